@@ -1,0 +1,159 @@
+"""Mirror of rayca-soft's renderer surface on top of the C ABI: `Config` (config.rs:10-49),
+`IntegratorStrategy`, `SamplerStrategy`, `SoftRenderer` with `draw(scene, image)` (scene.rs:88-154).
+All compute happens in librayca_hip.so on the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import abi, lib
+from .model import Image, Scene, create_default_model, flatten
+
+
+class IntegratorStrategy:
+    Scratcher, Raytracer, Flat, AnalyticDirect, Direct, Pathtracer = range(6)
+
+
+class SamplerStrategy:
+    NONE, Nee, Hemisphere, Cosine, Brdf, Mis = range(6)
+
+
+@dataclass
+class Config:
+    """rayca_soft::Config with the reference's defaults (config.rs:10-49)."""
+    bvh: bool = True
+    light_samples: int = 1
+    light_stratify: bool = False
+    samples_per_pixel: int = 1
+    russian_roulette: bool = False
+    direct_sampler: int = SamplerStrategy.Nee
+    indirect_sampler: int = SamplerStrategy.Cosine
+    integrator: int = IntegratorStrategy.Pathtracer
+    max_depth: int = 5
+    gamma: float = 1.0
+    seed: int = 0
+
+    def to_abi(self) -> abi.RaycaConfig:
+        c = abi.RaycaConfig()
+        c.bvh, c.light_samples, c.light_stratify = int(self.bvh), self.light_samples, int(self.light_stratify)
+        c.samples_per_pixel, c.russian_roulette = self.samples_per_pixel, int(self.russian_roulette)
+        c.direct_sampler, c.indirect_sampler, c.integrator = self.direct_sampler, self.indirect_sampler, self.integrator
+        c.max_depth, c.gamma, c.seed = self.max_depth, self.gamma, self.seed
+        return c
+
+
+class DeviceScene:
+    """Owns a RaycaScene handle: the device-resident scene + BVH (first half of draw, scene.rs:90-99)."""
+
+    def __init__(self, desc: abi.SceneDesc, config: Optional[Config] = None, device: int = 0,
+                 builder: int = abi.BUILDER_REFERENCE):
+        self._lib = lib.load()
+        self.desc = desc
+        cfg = (config or Config()).to_abi()
+        opts = abi.RaycaBuildOptions()
+        opts.builder, opts.device = builder, device
+        h = C.c_void_p()
+        lib.check(self._lib.rayca_hip_scene_create(desc.ptr(), C.byref(cfg), C.byref(opts), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.rayca_hip_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def info(self) -> dict:
+        i = abi.RaycaSceneInfo()
+        lib.check(self._lib.rayca_hip_scene_info(self.handle, C.byref(i)))
+        return i.as_dict()
+
+    def primitive_order(self) -> np.ndarray:
+        n = self.info()["triangle_count"] + self.info()["sphere_count"]
+        out = np.zeros(n, np.uint32)
+        lib.check(self._lib.rayca_hip_scene_primitive_order(self.handle, out.ctypes.data, n))
+        return out
+
+    @staticmethod
+    def _opts(traversal, collect_stats, tile, stream):
+        o = abi.RaycaRenderOptions()
+        o.traversal, o.collect_stats = traversal, int(collect_stats)
+        if tile is not None:
+            o.tile.part, o.tile.parts, o.tile.band_rows = tile
+        o.stream = stream
+        return o
+
+    def tile_rows(self, tile, height) -> int:
+        t = abi.RaycaTile()
+        t.part, t.parts, t.band_rows = tile
+        return self._lib.rayca_hip_tile_rows(C.byref(t), height)
+
+    def render(self, config: Config, width: int, height: int, *, traversal=abi.TRAVERSAL_ORDERED,
+               collect_stats=False, tile=None, want_rgba8=True, want_f32=True):
+        """rayca_hip_render: host outputs. Returns (rgba8 | None, rgba32f | None, stats dict)."""
+        rows = height if tile is None else self.tile_rows(tile, height)
+        u8 = np.zeros((rows, width, 4), np.uint8) if want_rgba8 else None
+        f32 = np.zeros((rows, width, 4), np.float32) if want_f32 else None
+        st = abi.RaycaStats()
+        cfg = config.to_abi()
+        o = self._opts(traversal, collect_stats, tile, None)
+        lib.check(self._lib.rayca_hip_render(self.handle, C.byref(cfg), width, height, C.byref(o),
+                                             u8.ctypes.data if u8 is not None else None,
+                                             f32.ctypes.data if f32 is not None else None, C.byref(st)))
+        return u8, f32, st.as_dict()
+
+    def render_device(self, config: Config, width: int, height: int, d_rgba8: int, d_f32: int = 0, *,
+                      traversal=abi.TRAVERSAL_ORDERED, collect_stats=False, tile=None, stream=None,
+                      want_stats=False):
+        """rayca_hip_render_device: outputs stay in device memory (pointers as ints)."""
+        st = abi.RaycaStats()
+        cfg = config.to_abi()
+        o = self._opts(traversal, collect_stats, tile, stream)
+        lib.check(self._lib.rayca_hip_render_device(self.handle, C.byref(cfg), width, height, C.byref(o),
+                                                    d_rgba8 or None, d_f32 or None,
+                                                    C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    def trace_rays(self, rays: np.ndarray, *, traversal=abi.TRAVERSAL_ORDERED, collect_stats=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        t = np.zeros(n, np.float32)
+        prim = np.zeros(n, np.uint32)
+        uv = np.zeros((n, 2), np.float32)
+        st = abi.RaycaStats()
+        o = self._opts(traversal, collect_stats, None, None)
+        lib.check(self._lib.rayca_hip_trace_rays(self.handle, C.byref(o), n, rays.ctypes.data, t.ctypes.data,
+                                                 prim.ctypes.data, uv.ctypes.data, C.byref(st)))
+        return t, prim, uv, st.as_dict()
+
+
+class SoftRenderer:
+    """Drop-in for rayca_soft::SoftRenderer (scene.rs:11-14): `draw(scene, image)` renders `scene`
+    with camera_draw_infos[0] into `image` (RGBA8).  Like the reference it rebuilds the BVH on
+    every draw; use DeviceScene directly to amortise the build."""
+
+    def __init__(self, config: Optional[Config] = None, device: int = 0):
+        self.config = config or Config()
+        self.device = device
+        self.last_stats = None
+
+    @staticmethod
+    def new_with_config(config: Config) -> "SoftRenderer":
+        return SoftRenderer(config)
+
+    @staticmethod
+    def create_default_model():
+        return create_default_model()
+
+    def draw(self, scene: Scene, image: Image) -> None:
+        if image.color_type != abi.COLOR_RGBA8:
+            raise ValueError("draw() writes RGBA8 images (scene.rs:117)")
+        ds = DeviceScene(flatten(scene), self.config, self.device)
+        try:
+            u8, _, self.last_stats = ds.render(self.config, image.width, image.height, want_f32=False)
+            image.data[...] = u8
+        finally:
+            ds.close()
