@@ -1,0 +1,84 @@
+// device_types.hpp -- PODs shared by the host launcher and the gfx950 kernels.
+#pragma once
+
+#include <cstdint>
+
+#include "host_scene.hpp"
+#include "rayca_math.hpp"
+
+namespace rayca {
+
+struct DevMaterial {  // RaycaMaterial, reordered for 16-B loads
+  float color[4];
+  float ambient[4], emission[4], diffuse[4], specular[4];
+  uint32_t kind, albedo_texture, normal_texture, metallic_roughness_texture;
+  float metallic_factor, roughness_factor, shininess;
+  uint32_t emissive;  // precomputed PhongMaterial::is_emissive  (material/phong.rs:54-56)
+};
+
+struct DevTexture {
+  uint32_t width, height, color_type, pad;
+  uint64_t byte_offset;
+};
+
+struct DevLight {
+  uint32_t kind, material;
+  float intensity, pad;
+  float color[4];
+  float attenuation[4];
+  float ab[4], ac[4];
+  float position[4];  // Point3::from(trs.get_translation()) of the node-LOCAL trs (nee.rs:133-134)
+  float normal[4];    // quad: normalized(ab x ac)  (light/quad.rs:36-38)
+  float area, pad1, pad2, pad3;
+};
+
+struct DevScene {
+  const float4* nodes;  // 4 x float4 per DevNode
+  const float* tris;    // 9 floats per primitive slot (world-space v0,v1,v2)
+  const PrimExt* ext;   // per primitive slot
+  const DevMaterial* materials;
+  const DevLight* lights;
+  const DevTexture* textures;
+  const uint8_t* image_bytes;
+  uint32_t material_count, light_count, texture_count, prim_count;
+  uint32_t root_ref;
+  float root_min[3], root_max[3];
+  float cull_abs;  // absolute slack of the best-t cull (see trace())
+  uint32_t tri_soa;  // 0: 36-B AoS triangles, 1: nine SoA planes of prim_count floats
+};
+
+// One launch renders `rows` packed rows of a width x height frame.
+struct FrameParams {
+  uint32_t width, height;       // full frame
+  uint32_t rows;                // rows rendered by this call (packed output)
+  uint32_t part, parts, band;   // row r of the output is frame row ((r/band)*parts+part)*band + r%band
+  uint32_t tiles_x, tile_count; // 8x8 pixel tiles over the packed output
+  float inv_width, inv_height, aspect, angle;
+  Trs camera;                   // camera WORLD transform (scene.rs:112)
+  // Config
+  uint32_t integrator, direct_sampler, indirect_sampler, light_samples, light_stratify, strate_count;
+  uint32_t max_depth, russian_roulette, seed, spp, sample;
+  float sub_x, sub_y;           // ix*step + offset, iy*step + offset of this sample (scene.rs:125-137)
+  float inv_gamma;
+};
+
+struct TraceCounters {
+  unsigned long long boxes, tris, shaded, shadow, bounce;
+};
+
+// ray queue entry between two generations (32 B)
+struct QueuedRay {
+  float ox, oy, oz, dx, dy, dz;
+  uint32_t pixel;  // index into the packed output (r*width + x)
+  uint32_t key;    // RNG key of the path vertex this ray leads to
+};
+
+// per generation, per pixel record used to fold the path back in the reference's evaluation order
+enum : uint32_t { kVertexNone = 0, kVertexLit = 1, kVertexEmissive = 2, kVertexLitNoIndirect = 3 };
+
+struct WorkQueue {
+  uint32_t* heads;   // 8 counters, one per XCD partition (device memory, zeroed before launch)
+  uint32_t total;    // number of 64-wide batches
+};
+
+}  // namespace rayca

@@ -1,0 +1,642 @@
+// host_scene.cpp -- scene-graph flattening and the reference-equivalent BVH build.
+//
+// What the reference does at the top of every draw (rayca-soft/src/scene.rs:90-99):
+//   SceneDrawInfo::new      scene.rs:190-282        world transforms + draw-info lists
+//   BvhScene::from_scene    bvh/primitive.rs:194-395 one BvhModel (primitive list) per model
+//   Tlas::new               bvh/tlas.rs:248-269     one BLAS per model (SAH, bvh/blas.rs:229-316)
+//                                                   + median-split TLAS (bvh/tlas.rs:74-134)
+// The tree produced here has exactly the reference's topology and primitive order (so depth ties
+// resolve identically); only the evaluation strategy differs: the 63 x 3 SAH candidates of
+// find_best_split_plane (blas.rs:93-123) are priced from one binned sweep per axis instead of 189
+// passes over the primitives, and disjoint subtrees are built on separate host threads.
+#include "host_scene.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <future>
+#include <thread>
+
+namespace rayca {
+namespace {
+
+struct Box {
+  F4 a, b;
+};
+inline Box empty_box() { return Box{point3(FLT_MAX, FLT_MAX, FLT_MAX), point3(-FLT_MAX, -FLT_MAX, -FLT_MAX)}; }
+inline Box origin_box() { return Box{point3(0, 0, 0), point3(0, 0, 0)}; }  // AABB::default()  aabb.rs:9-13
+inline void grow(Box& bx, F4 p) {
+  bx.a = vmin(bx.a, p);
+  bx.b = vmax(bx.b, p);
+}
+inline float area(const Box& bx) {  // aabb.rs:20-23
+  const F4 e = as_vec(bx.b - bx.a);
+  return e.x * e.y + e.y * e.z + e.z * e.x;
+}
+inline float axis_of(F4 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+inline Trs trs_from_abi(const RaycaTrs& t) {
+  return Trs{vec3(t.translation[0], t.translation[1], t.translation[2]), f4(t.rotation[0], t.rotation[1], t.rotation[2], t.rotation[3]),
+             vec3(t.scale[0], t.scale[1], t.scale[2])};
+}
+
+float sphere_world_radius(const HostPrim& p, const Trs& t) {  // sphere.rs:90-92
+  return p.radius * fmaxf(fmaxf(t.scale.x, t.scale.y), fmaxf(t.scale.z, t.scale.w));
+}
+
+// grow a box by a primitive the way AABB::grow_primitive does (aabb.rs:62-72)
+void grow_primitive(Box& bx, const HostPrim& p, const Trs& t) {
+  if (p.kind == RAYCA_GEOMETRY_TRIANGLE_MESH) {
+    grow(bx, p.wp[0]);
+    grow(bx, p.wp[1]);
+    grow(bx, p.wp[2]);
+  } else {
+    const float r = sphere_world_radius(p, t);
+    const F4 c = trs_apply_point(t, p.center);
+    grow(bx, c + vec3(-r, 0, 0));
+    grow(bx, c + vec3(r, 0, 0));
+    grow(bx, c + vec3(0, -r, 0));
+    grow(bx, c + vec3(0, r, 0));
+    grow(bx, c + vec3(0, 0, -r));
+    grow(bx, c + vec3(0, 0, r));
+  }
+}
+
+void cache_world(HostPrim& p, const Trs& t) {
+  if (p.kind == RAYCA_GEOMETRY_TRIANGLE_MESH) {
+    for (int i = 0; i < 3; ++i) p.wp[i] = trs_apply_point(t, p.p[i]);  // Triangle::get_vertex  triangle.rs:67-69
+    p.wcentroid = to_point(trs_apply_vec(t, p.centroid));              // primitive.rs:71-77 -> triangle.rs:161-163
+    F4 mn = point3(FLT_MAX, FLT_MAX, FLT_MAX), mx = point3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int i = 0; i < 3; ++i) {
+      mn = vmin(mn, p.wp[i]);
+      mx = vmax(mx, p.wp[i]);
+    }
+    p.wmin = mn;
+    p.wmax = mx;
+  } else {
+    const float r = sphere_world_radius(p, t);
+    const F4 c = trs_apply_point(t, p.center);
+    p.wcentroid = c;
+    p.wmin = c - vec3(r, r, r);  // sphere.rs:170-178
+    p.wmax = c + vec3(r, r, r);
+    p.wp[0] = p.wp[1] = p.wp[2] = point3(0, 0, 0);
+  }
+}
+
+// ---- BLAS build --------------------------------------------------------------------------------
+struct BuildNode {
+  Box bounds;
+  uint32_t offset = 0, count = 0;  // primitive range (leaf) -- count == 0 => inner
+  int32_t left = -1, right = -1;   // indices into the arena
+};
+
+struct BlasBuilder {
+  const HostScene* scene;
+  std::vector<uint32_t>* order;  // indices into scene->prims, partitioned in place
+  uint32_t max_depth;
+  unsigned parallel_levels;
+
+  const HostPrim& prim(uint32_t slot) const { return scene->prims[(*order)[slot]]; }
+
+  Box range_bounds(uint32_t offset, uint32_t count) const {  // BvhNode::new  blas.rs:27-36
+    Box bx = empty_box();
+    for (uint32_t i = offset; i < offset + count; ++i) {
+      bx.a = vmin(bx.a, prim(i).wmin);
+      bx.b = vmax(bx.b, prim(i).wmax);
+    }
+    return bx;
+  }
+
+  // find_best_split_plane (blas.rs:93-123) + evaluate_sah (blas.rs:64-89), exact binned form.
+  // A primitive is left of plane i iff centroid < pos_i; pos_i is non-decreasing in i, so it is left
+  // of exactly the planes i > k with k = #{i : pos_i <= centroid}.  Unions of min/max are exact, so
+  // each of the 63 (count, box) pairs -- and therefore each cost -- equals the literal evaluation.
+  void best_split(const BuildNode& node, int& best_axis, float& split_pos, float& best_cost) const {
+    best_cost = FLT_MAX;
+    best_axis = 0;
+    split_pos = 0.0f;
+    for (int axis = 0; axis < 3; ++axis) {
+      const float bmin = axis_of(node.bounds.a, axis), bmax = axis_of(node.bounds.b, axis);
+      if (bmin == bmax) continue;
+      const float scale = (bmax - bmin) / 64.0f;
+      float pos[64];
+      pos[0] = -FLT_MAX;
+      for (int i = 1; i < 64; ++i) pos[i] = bmin + (float)i * scale;
+      Box bins[64];
+      uint32_t cnt[64];
+      for (int b = 0; b < 64; ++b) {
+        bins[b] = empty_box();
+        cnt[b] = 0;
+      }
+      for (uint32_t s = node.offset; s < node.offset + node.count; ++s) {
+        const HostPrim& p = prim(s);
+        const float c = axis_of(p.wcentroid, axis);
+        int k;
+        if (c != c) {
+          k = 63;  // NaN: never `<` any plane
+        } else {
+          // k = number of planes j in 1..63 with pos[j] <= c  (upper bound in a monotone array)
+          int lo = 1, hi = 64;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pos[mid] <= c) lo = mid + 1;
+            else hi = mid;
+          }
+          k = lo - 1;
+        }
+        cnt[k]++;
+        grow_primitive(bins[k], p, scene->world_trs[p.node]);
+      }
+      Box lbox[65], rbox[65];
+      uint32_t lcnt[65], rcnt[65];
+      lbox[0] = origin_box();
+      lcnt[0] = 0;
+      for (int b = 0; b < 64; ++b) {
+        lbox[b + 1] = lbox[b];
+        lcnt[b + 1] = lcnt[b] + cnt[b];
+        if (cnt[b]) {
+          lbox[b + 1].a = vmin(lbox[b + 1].a, bins[b].a);
+          lbox[b + 1].b = vmax(lbox[b + 1].b, bins[b].b);
+        }
+      }
+      rbox[64] = origin_box();
+      rcnt[64] = 0;
+      for (int b = 63; b >= 0; --b) {
+        rbox[b] = rbox[b + 1];
+        rcnt[b] = rcnt[b + 1] + cnt[b];
+        if (cnt[b]) {
+          rbox[b].a = vmin(rbox[b].a, bins[b].a);
+          rbox[b].b = vmax(rbox[b].b, bins[b].b);
+        }
+      }
+      for (int i = 1; i < 64; ++i) {
+        float cost = (float)lcnt[i] * area(lbox[i]) + (float)rcnt[i] * area(rbox[i]);
+        if (!(cost > 0.0f)) cost = FLT_MAX;
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_axis = axis;
+          split_pos = pos[i];
+        }
+      }
+    }
+  }
+
+  // Blas::set_primitives_recursive  blas.rs:261-316.  Builds the subtree below arena[idx]; new
+  // nodes go to `arena` (thread-local when running as a task).
+  void split(std::vector<BuildNode>& arena, int32_t idx, uint32_t level) const {
+    if (level >= max_depth) return;
+    BuildNode node = arena[idx];
+    int axis;
+    float pos, cost;
+    best_split(node, axis, pos, cost);
+    const float no_split_cost = (float)node.count * area(node.bounds);
+    if (cost > no_split_cost) return;
+    uint32_t i = node.offset, j = node.offset + node.count;
+    std::vector<uint32_t>& ord = *order;
+    while (i < j) {  // partition-in-place, exactly the reference's swap sequence (blas.rs:279-289)
+      if (axis_of(scene->prims[ord[i]].wcentroid, axis) < pos) {
+        ++i;
+      } else {
+        std::swap(ord[i], ord[j - 1]);
+        --j;
+      }
+    }
+    const uint32_t left_count = i - node.offset, right_count = node.count - left_count;
+    if (left_count == 0 || right_count == 0) return;
+    BuildNode l, r;
+    l.offset = node.offset;
+    l.count = left_count;
+    l.bounds = range_bounds(l.offset, l.count);
+    r.offset = node.offset + left_count;
+    r.count = right_count;
+    r.bounds = range_bounds(r.offset, r.count);
+    if (level < parallel_levels && node.count > 8192) {
+      // children in private arenas, spliced afterwards; ranges are disjoint so partitioning is safe
+      std::vector<BuildNode> la{l}, ra{r};
+      auto fut = std::async(std::launch::async, [&] { split(la, 0, level + 1); });
+      split(ra, 0, level + 1);
+      fut.get();
+      const int32_t lbase = (int32_t)arena.size();
+      for (auto n : la) {
+        if (n.left >= 0) {
+          n.left += lbase;
+          n.right += lbase;
+        }
+        arena.push_back(n);
+      }
+      const int32_t rbase = (int32_t)arena.size();
+      for (auto n : ra) {
+        if (n.left >= 0) {
+          n.left += rbase;
+          n.right += rbase;
+        }
+        arena.push_back(n);
+      }
+      arena[idx].left = lbase;
+      arena[idx].right = rbase;
+    } else {
+      const int32_t li = (int32_t)arena.size();
+      arena.push_back(l);
+      const int32_t ri = (int32_t)arena.size();
+      arena.push_back(r);
+      arena[idx].left = li;
+      arena[idx].right = ri;
+      split(arena, li, level + 1);
+      split(arena, ri, level + 1);
+    }
+    arena[idx].count = 0;  // inner
+  }
+};
+
+// arena tree -> the reference's node numbering: a node's two children are appended when the node
+// is split, and splits happen in DFS pre-order (blas.rs:302-311).
+void to_reference_layout(const std::vector<BuildNode>& arena, std::vector<RefNode>& out) {
+  out.clear();
+  out.push_back(RefNode{arena[0].bounds.a, arena[0].bounds.b, arena[0].offset, arena[0].count});
+  out.push_back(RefNode{point3(0, 0, 0), point3(0, 0, 0), 0, 0});  // slot 1 unused (blas.rs:254-256)
+  struct Item { int32_t arena_idx; uint32_t ref_idx; };
+  std::vector<Item> stack{{0, 0}};
+  while (!stack.empty()) {
+    const Item it = stack.back();
+    stack.pop_back();
+    const BuildNode& n = arena[it.arena_idx];
+    if (n.left < 0) continue;
+    const uint32_t li = (uint32_t)out.size();
+    const BuildNode &l = arena[n.left], &r = arena[n.right];
+    out.push_back(RefNode{l.bounds.a, l.bounds.b, l.offset, l.count});
+    out.push_back(RefNode{r.bounds.a, r.bounds.b, r.offset, r.count});
+    out[it.ref_idx].offset = li;
+    out[it.ref_idx].count = 0;
+    stack.push_back({n.right, li + 1});  // right is split after the whole left subtree
+    stack.push_back({n.left, li});
+  }
+}
+
+// ---- TLAS build  bvh/tlas.rs:74-134 --------------------------------------------------------------
+struct TNode {
+  Box bounds;
+  int32_t left = -1, right = -1;
+  uint32_t offset = 0, count = 0;
+};
+
+void tlas_split(std::vector<TNode>& tn, int32_t self, std::vector<uint32_t>& blas_order, const std::vector<Box>& blas_root,
+                uint32_t offset, uint32_t count) {
+  TNode n;
+  n.offset = offset;
+  n.count = count;
+  n.bounds = empty_box();
+  for (uint32_t i = offset; i < offset + count; ++i) {
+    n.bounds.a = vmin(n.bounds.a, blas_root[blas_order[i]].a);
+    n.bounds.b = vmax(n.bounds.b, blas_root[blas_order[i]].b);
+  }
+  const F4 extent = as_vec(n.bounds.b - n.bounds.a);
+  int axis = 0;
+  if (extent.y > extent.x) axis = 1;
+  if (extent.z > axis_of(extent, axis)) axis = 2;
+  const float split_pos = axis_of(n.bounds.a, axis) + axis_of(extent, axis) * 0.5f;
+  uint32_t i = offset, j = offset + count;
+  while (i < j) {
+    const Box& rb = blas_root[blas_order[i]];
+    const F4 centroid = to_point(as_vec(rb.b - rb.a) / 2.0f);  // AABB::get_centroid: the half-extent (aabb.rs:95-97)
+    if (axis_of(centroid, axis) < split_pos) {
+      ++i;
+    } else {
+      std::swap(blas_order[i], blas_order[j - 1]);
+      --j;
+    }
+  }
+  const uint32_t left_count = i - offset, right_count = count - left_count;
+  tn[self] = n;
+  if (left_count > 0 && right_count > 0) {
+    const int32_t l = (int32_t)tn.size();
+    tn.emplace_back();
+    tlas_split(tn, l, blas_order, blas_root, offset, left_count);
+    const int32_t r = (int32_t)tn.size();
+    tn.emplace_back();
+    tlas_split(tn, r, blas_order, blas_root, offset + left_count, right_count);
+    tn[self].left = l;
+    tn[self].right = r;
+    tn[self].count = 0;
+  }
+}
+
+// ---- device layout -------------------------------------------------------------------------------
+struct DevBuilder {
+  HostScene& s;
+  std::vector<uint32_t> blas_base;  // first global primitive slot of each BLAS (TLAS order)
+
+  static void put_box(DevNode& n, int side, const Box& b) {
+    if (side == 0) {
+      n.q[0] = b.a.x; n.q[1] = b.a.y; n.q[2] = b.a.z; n.q[3] = b.b.x; n.q[4] = b.b.y; n.q[5] = b.b.z;
+    } else {
+      n.q[6] = b.a.x; n.q[7] = b.a.y; n.q[8] = b.a.z; n.q[9] = b.b.x; n.q[10] = b.b.y; n.q[11] = b.b.z;
+    }
+  }
+  static uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafFlag | ((count - 1u) << 25) | first; }
+
+  uint32_t new_node() {
+    s.dev_nodes.emplace_back();
+    std::memset(&s.dev_nodes.back(), 0, sizeof(DevNode));
+    return (uint32_t)s.dev_nodes.size() - 1;
+  }
+  // a leaf range: one packed ref, or a chain of nodes re-testing the same box for > 64 primitives
+  uint32_t emit_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t depth) {
+    if (count <= kLeafMaxPrims) {
+      s.max_depth = std::max(s.max_depth, depth);
+      return leaf_ref(first, count == 0 ? 1 : count);
+    }
+    const uint32_t n = new_node();
+    put_box(s.dev_nodes[n], 0, box);
+    put_box(s.dev_nodes[n], 1, box);
+    s.dev_nodes[n].left = leaf_ref(first, kLeafMaxPrims);
+    s.max_depth = std::max(s.max_depth, depth + 1);
+    const uint32_t rest = emit_leaf(first + kLeafMaxPrims, count - kLeafMaxPrims, box, depth + 1);
+    s.dev_nodes[n].right = rest;
+    return n;
+  }
+  uint32_t emit_blas_node(const HostBlas& bl, uint32_t base, uint32_t ref_idx, uint32_t depth) {
+    // iterative descent would be needed for degenerate 255-deep trees only; recursion depth <= 255
+    const RefNode& rn = bl.nodes[ref_idx];
+    const Box box{rn.a, rn.b};
+    if (rn.count != 0 || (ref_idx == 0 && bl.prims.empty())) return emit_leaf(base + rn.offset, rn.count, box, depth);
+    const uint32_t n = new_node();
+    const RefNode &l = bl.nodes[rn.offset], &r = bl.nodes[rn.offset + 1];
+    put_box(s.dev_nodes[n], 0, Box{l.a, l.b});
+    put_box(s.dev_nodes[n], 1, Box{r.a, r.b});
+    const uint32_t lr = emit_blas_node(bl, base, rn.offset, depth + 1);
+    s.dev_nodes[n].left = lr;
+    const uint32_t rr = emit_blas_node(bl, base, rn.offset + 1, depth + 1);
+    s.dev_nodes[n].right = rr;
+    return n;
+  }
+  // TLAS leaf holding blas [offset, offset+count): BLAS roots tested one after the other
+  uint32_t emit_blas_chain(uint32_t offset, uint32_t count, const Box& leaf_box, uint32_t depth) {
+    if (count == 1) return emit_blas_node(s.blas[offset], blas_base[offset], 0, depth);
+    const uint32_t n = new_node();
+    const RefNode& root = s.blas[offset].nodes[0];
+    put_box(s.dev_nodes[n], 0, Box{root.a, root.b});
+    put_box(s.dev_nodes[n], 1, leaf_box);
+    const uint32_t lr = emit_blas_node(s.blas[offset], blas_base[offset], 0, depth + 1);
+    s.dev_nodes[n].left = lr;
+    const uint32_t rr = emit_blas_chain(offset + 1, count - 1, leaf_box, depth + 1);
+    s.dev_nodes[n].right = rr;
+    return n;
+  }
+  uint32_t emit_tlas(const std::vector<TNode>& tn, int32_t idx, uint32_t depth) {
+    const TNode& t = tn[idx];
+    if (t.left < 0) return emit_blas_chain(t.offset, t.count, t.bounds, depth);
+    const uint32_t n = new_node();
+    put_box(s.dev_nodes[n], 0, tn[t.left].bounds);
+    put_box(s.dev_nodes[n], 1, tn[t.right].bounds);
+    const uint32_t lr = emit_tlas(tn, t.left, depth + 1);
+    s.dev_nodes[n].left = lr;
+    const uint32_t rr = emit_tlas(tn, t.right, depth + 1);
+    s.dev_nodes[n].right = rr;
+    return n;
+  }
+};
+
+bool fetch_index(const RaycaSceneDesc& d, const RaycaPrimitive& p, uint32_t i, uint32_t& out) {
+  const uint64_t off = p.index_byte_offset;
+  switch (p.index_type) {
+    case RAYCA_INDEX_U8:
+      if (off + i >= d.index_byte_count) return false;
+      out = d.index_bytes[off + i];
+      return true;
+    case RAYCA_INDEX_U16: {
+      if (off + 2ull * i + 2 > d.index_byte_count) return false;
+      uint16_t v;
+      std::memcpy(&v, d.index_bytes + off + 2ull * i, 2);
+      out = v;
+      return true;
+    }
+    case RAYCA_INDEX_U32: {
+      if (off + 4ull * i + 4 > d.index_byte_count) return false;
+      std::memcpy(&out, d.index_bytes + off + 4ull * i, 4);
+      return true;
+    }
+    default:
+      return false;  // panic!("Index type not supported")  primitive.rs:258
+  }
+}
+
+void set_ext(PrimExt& e, int k, Color c, F4 n, F4 t, F4 b, F2 uv) {
+  e.color[k][0] = c.r; e.color[k][1] = c.g; e.color[k][2] = c.b; e.color[k][3] = c.a;
+  e.normal[k][0] = n.x; e.normal[k][1] = n.y; e.normal[k][2] = n.z;
+  e.tangent[k][0] = t.x; e.tangent[k][1] = t.y; e.tangent[k][2] = t.z;
+  e.bitangent[k][0] = b.x; e.bitangent[k][1] = b.y; e.bitangent[k][2] = b.z;
+  e.uv[k][0] = uv.x; e.uv[k][1] = uv.y;
+}
+
+}  // namespace
+
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& s, std::string& err) {
+  if (d.abi_version != RAYCA_ABI_VERSION) { err = "abi version mismatch"; return RAYCA_ERR_BAD_ARG; }
+  if (d.node_count && !d.nodes) { err = "nodes is null"; return RAYCA_ERR_BAD_ARG; }
+  if (d.vertex_count && !d.positions) { err = "positions is null"; return RAYCA_ERR_BAD_ARG; }
+  const uint32_t N = d.node_count;
+
+  // ---- SceneDrawInfo::new: world(i) = world(parent) * local(i)  (scene.rs:213-215,228,242) ----
+  s.local_trs.resize(N);
+  s.world_trs.resize(N);
+  std::vector<std::vector<uint32_t>> children(N);
+  std::vector<uint32_t> tops;
+  for (uint32_t i = 0; i < N; ++i) {
+    const RaycaNode& n = d.nodes[i];
+    if (n.parent >= (int32_t)i) { err = "node " + std::to_string(i) + ": parent must precede child"; return RAYCA_ERR_BAD_ARG; }
+    s.local_trs[i] = trs_from_abi(n.trs);
+    if (n.parent < 0) {
+      s.world_trs[i] = s.local_trs[i];
+      tops.push_back(i);
+    } else {
+      s.world_trs[i] = trs_compose(s.world_trs[n.parent], s.local_trs[i]);
+      children[n.parent].push_back(i);
+    }
+  }
+  // traversal order = DFS pre-order (children ascending)
+  std::vector<uint32_t> order;
+  order.reserve(N);
+  {
+    std::vector<uint32_t> stack(tops.rbegin(), tops.rend());
+    while (!stack.empty()) {
+      const uint32_t n = stack.back();
+      stack.pop_back();
+      order.push_back(n);
+      for (auto it = children[n].rbegin(); it != children[n].rend(); ++it) stack.push_back(*it);
+    }
+  }
+  std::vector<uint32_t> mesh_nodes, light_nodes;
+  for (uint32_t n : order) {
+    const RaycaNode& nd = d.nodes[n];
+    if (nd.mesh != RAYCA_NONE) {
+      if (nd.mesh >= d.mesh_count) { err = "mesh index out of range"; return RAYCA_ERR_BAD_ARG; }
+      mesh_nodes.push_back(n);
+    }
+    if (nd.light != RAYCA_NONE) {
+      if (nd.light >= d.light_count) { err = "light index out of range"; return RAYCA_ERR_BAD_ARG; }
+      light_nodes.push_back(n);
+    }
+    if (nd.camera != RAYCA_NONE && !s.has_camera) {
+      if (nd.camera >= d.camera_count) { err = "camera index out of range"; return RAYCA_ERR_BAD_ARG; }
+      s.has_camera = true;
+      s.camera_node = n;
+      s.camera_yfov = d.cameras[nd.camera].yfov_radians;
+    }
+  }
+  for (uint32_t n : light_nodes) {
+    const RaycaLight& l = d.lights[d.nodes[n].light];
+    HostLight hl;
+    hl.kind = l.kind;
+    hl.node = n;
+    hl.material = l.material;
+    hl.intensity = l.intensity;
+    hl.color = rgba(l.color[0], l.color[1], l.color[2], l.color[3]);
+    hl.attenuation = vec3(l.attenuation[0], l.attenuation[1], l.attenuation[2]);
+    hl.ab = vec3(l.ab[0], l.ab[1], l.ab[2]);
+    hl.ac = vec3(l.ac[0], l.ac[1], l.ac[2]);
+    hl.local = s.local_trs[n];
+    s.lights.push_back(hl);
+  }
+  s.materials.assign(d.materials, d.materials + d.material_count);
+  s.textures.assign(d.textures, d.textures + d.texture_count);
+  s.images.assign(d.images, d.images + d.image_count);
+  s.image_bytes.assign(d.image_bytes, d.image_bytes + d.image_byte_count);
+
+  // ---- BvhScene::from_scene: models in ascending id; per model meshes then quad lights ----------
+  std::vector<uint32_t> models;
+  for (uint32_t n : mesh_nodes) models.push_back(d.nodes[n].model);
+  for (uint32_t n : light_nodes)
+    if (d.lights[d.nodes[n].light].kind == RAYCA_LIGHT_QUAD) models.push_back(d.nodes[n].model);
+  std::sort(models.begin(), models.end());
+  models.erase(std::unique(models.begin(), models.end()), models.end());
+
+  std::vector<HostBlas> blas(models.size());
+  for (size_t m = 0; m < models.size(); ++m) {
+    blas[m].model = models[m];
+    for (uint32_t node : mesh_nodes) {
+      if (d.nodes[node].model != models[m]) continue;
+      const RaycaMesh& mesh = d.meshes[d.nodes[node].mesh];
+      const Trs& trs = s.world_trs[node];
+      const Mat3 tangent_matrix = mat3_from_trs(trs);                             // primitive.rs:203-204
+      const Mat3 normal_matrix = mat3_transpose(mat3_from_inverse_trs(trs));      // primitive.rs:206-207
+      for (uint32_t pi = mesh.first_primitive; pi < mesh.first_primitive + mesh.primitive_count; ++pi) {
+        if (pi >= d.primitive_count) { err = "primitive index out of range"; return RAYCA_ERR_BAD_ARG; }
+        const RaycaPrimitive& p = d.primitives[pi];
+        if (p.geometry == RAYCA_GEOMETRY_SPHERE) {  // from_sphere  primitive.rs:262-274
+          HostPrim hp{};
+          hp.kind = RAYCA_GEOMETRY_SPHERE;
+          hp.node = node;
+          hp.material = p.material;
+          hp.center = point3(p.sphere_center[0], p.sphere_center[1], p.sphere_center[2]);
+          hp.radius = p.sphere_radius;
+          hp.ext.material = p.material;
+          hp.ext.kind = hp.kind;
+          hp.ext.node = node;
+          hp.src = (uint32_t)s.prims.size();
+          blas[m].prims.push_back(hp.src);
+          s.prims.push_back(hp);
+          s.sphere_count++;
+          continue;
+        }
+        for (uint32_t t = 0; t < p.index_count / 3; ++t) {  // from_triangle_mesh_impl  primitive.rs:209-234
+          HostPrim hp{};
+          hp.kind = RAYCA_GEOMETRY_TRIANGLE_MESH;
+          hp.node = node;
+          hp.material = p.material;
+          for (int k = 0; k < 3; ++k) {
+            uint32_t idx;
+            if (!fetch_index(d, p, t * 3 + (uint32_t)k, idx)) { err = "index fetch out of range or unsupported index type"; return RAYCA_ERR_BAD_ARG; }
+            if (idx >= p.vertex_count || p.first_vertex + idx >= d.vertex_count) { err = "vertex index out of range"; return RAYCA_ERR_BAD_ARG; }
+            const uint32_t v = p.first_vertex + idx;
+            hp.p[k] = point3(d.positions[3 * v], d.positions[3 * v + 1], d.positions[3 * v + 2]);
+            const Color c = d.colors ? rgba(d.colors[4 * v], d.colors[4 * v + 1], d.colors[4 * v + 2], d.colors[4 * v + 3]) : white();
+            const F4 nrm = d.normals ? vec3(d.normals[3 * v], d.normals[3 * v + 1], d.normals[3 * v + 2]) : vec3(0, 0, 1);
+            const F4 tan = d.tangents ? vec3(d.tangents[3 * v], d.tangents[3 * v + 1], d.tangents[3 * v + 2]) : vec3(0, 0, 0);
+            const F4 bit = d.bitangents ? vec3(d.bitangents[3 * v], d.bitangents[3 * v + 1], d.bitangents[3 * v + 2]) : vec3(0, 0, 0);
+            const F2 uv = d.uvs ? F2{d.uvs[2 * v], d.uvs[2 * v + 1]} : F2{0, 0};
+            set_ext(hp.ext, k, c, mat3_apply(normal_matrix, nrm), mat3_apply(tangent_matrix, tan), mat3_apply(tangent_matrix, bit), uv);
+          }
+          hp.centroid = ((to_vec(hp.p[0]) + to_vec(hp.p[1])) + to_vec(hp.p[2])) * 0.3333f;  // triangle.rs:59-63
+          hp.ext.material = p.material;
+          hp.ext.kind = hp.kind;
+          hp.ext.node = node;
+          hp.src = (uint32_t)s.prims.size();
+          blas[m].prims.push_back(hp.src);
+          s.prims.push_back(hp);
+          s.triangle_count++;
+        }
+      }
+    }
+    for (uint32_t node : light_nodes) {  // from_quad_light  primitive.rs:310-346
+      const RaycaLight& l = d.lights[d.nodes[node].light];
+      if (d.nodes[node].model != models[m] || l.kind != RAYCA_LIGHT_QUAD) continue;
+      const F4 ab = vec3(l.ab[0], l.ab[1], l.ab[2]), ac = vec3(l.ac[0], l.ac[1], l.ac[2]);
+      const F4 normal = normalized(cross(ab, ac));
+      const F4 qa = point3(0, 0, 0);
+      const F4 a = qa, b = qa + ab, dd = (qa + ab) + ac, c = qa + ac;
+      const F4 tri[2][3] = {{a, dd, b}, {a, c, dd}};
+      for (int t = 0; t < 2; ++t) {
+        HostPrim hp{};
+        hp.kind = RAYCA_GEOMETRY_TRIANGLE_MESH;
+        hp.node = node;
+        hp.material = l.material;
+        for (int k = 0; k < 3; ++k) {
+          hp.p[k] = tri[t][k];
+          set_ext(hp.ext, k, white(), normal, vec3(0, 0, 0), vec3(0, 0, 0), F2{0, 0});
+        }
+        hp.centroid = ((to_vec(hp.p[0]) + to_vec(hp.p[1])) + to_vec(hp.p[2])) * 0.3333f;
+        hp.ext.material = l.material;
+        hp.ext.kind = hp.kind;
+        hp.ext.node = node;
+        hp.src = (uint32_t)s.prims.size();
+        blas[m].prims.push_back(hp.src);
+        s.prims.push_back(hp);
+        s.triangle_count++;
+      }
+    }
+  }
+  for (HostPrim& p : s.prims) cache_world(p, s.world_trs[p.node]);
+
+  // ---- Tlas::new: one BLAS per model ------------------------------------------------------------
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  unsigned par_levels = 0;
+  while ((1u << par_levels) < hw) ++par_levels;
+  std::vector<Box> blas_root(blas.size());
+  for (size_t m = 0; m < blas.size(); ++m) {
+    BlasBuilder bb{&s, &blas[m].prims, use_bvh ? 255u : 0u, par_levels + 1};
+    std::vector<BuildNode> arena(1);
+    arena[0].offset = 0;
+    arena[0].count = (uint32_t)blas[m].prims.size();
+    arena[0].bounds = bb.range_bounds(0, arena[0].count);
+    if (arena[0].count > 0) bb.split(arena, 0, 0);
+    to_reference_layout(arena, blas[m].nodes);
+    blas_root[m] = arena[0].bounds;
+  }
+  std::vector<uint32_t> blas_order(blas.size());
+  for (size_t i = 0; i < blas.size(); ++i) blas_order[i] = (uint32_t)i;
+  std::vector<TNode> tn(1);
+  if (!blas.empty()) tlas_split(tn, 0, blas_order, blas_root, 0, (uint32_t)blas.size());
+  // store BLASes in TLAS order so that a TLAS range [offset, offset+count) indexes s.blas directly
+  s.blas.clear();
+  for (uint32_t b : blas_order) s.blas.push_back(std::move(blas[b]));
+
+  // ---- device layout ----------------------------------------------------------------------------
+  s.dev_nodes.clear();
+  s.prim_order.clear();
+  s.max_depth = 0;
+  if (!s.blas.empty()) {
+    DevBuilder db{s, {}};
+    uint32_t base = 0;
+    for (const HostBlas& bl : s.blas) {
+      db.blas_base.push_back(base);
+      for (uint32_t pi : bl.prims) s.prim_order.push_back(pi);
+      base += (uint32_t)bl.prims.size();
+    }
+    if (base > kLeafFirstMask) { err = "too many primitives for the packed leaf reference (max 33554431)"; return RAYCA_ERR_UNSUPPORTED; }
+    s.root_min = tn[0].bounds.a;
+    s.root_max = tn[0].bounds.b;
+    s.root_ref = db.emit_tlas(tn, 0, 0);
+  }
+  return RAYCA_OK;
+}
+
+}  // namespace rayca

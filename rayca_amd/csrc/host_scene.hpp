@@ -1,0 +1,98 @@
+// host_scene.hpp -- host half of SoftRenderer::draw before the pixel loop
+// (rayca-soft/src/scene.rs:90-99): SceneDrawInfo::new, BvhScene::from_scene, Tlas::builder().build,
+// then conversion of the two-level BVH into the device layout.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rayca_hip.h"
+#include "rayca_math.hpp"
+
+namespace rayca {
+
+// VertexExt (rayca-geometry/src/vertex.rs:64-72) x3 + material, as uploaded: 48 words per primitive.
+struct PrimExt {
+  float color[3][4];
+  float normal[3][3];
+  float tangent[3][3];
+  float bitangent[3][3];
+  float uv[3][2];
+  uint32_t material;
+  uint32_t kind;       // RAYCA_GEOMETRY_*
+  uint32_t node;       // world-transform index (spheres)
+};
+static_assert(sizeof(PrimExt) == 48 * 4, "PrimExt is 192 B");
+
+// BvhNode in the reference's layout (bvh/blas.rs:11-15): root 0, slot 1 unused, children adjacent.
+struct RefNode {
+  F4 a, b;
+  uint32_t offset, count;
+};
+
+// Device BVH node, 64 B: both children's boxes + packed child references.
+//   q0 = (l.min.x, l.min.y, l.min.z, l.max.x)   q1 = (l.max.y, l.max.z, r.min.x, r.min.y)
+//   q2 = (r.min.z, r.max.x, r.max.y, r.max.z)   q3 = (bits: left ref, right ref, 0, 0)
+// child ref: bit31 = leaf; leaf: bits30..25 = count-1 (<=64 primitives), bits24..0 = first primitive;
+// inner: node index.
+struct DevNode {
+  float q[12];
+  uint32_t left, right, pad0, pad1;
+};
+static_assert(sizeof(DevNode) == 64, "DevNode is 64 B");
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr uint32_t kLeafMaxPrims = 64;
+constexpr uint32_t kLeafFirstMask = 0x01FFFFFFu;
+
+struct HostLight {
+  uint32_t kind, node, material;
+  float intensity;
+  Color color;
+  F4 attenuation, ab, ac;
+  Trs local;  // node-LOCAL transform: what the samplers use (nee.rs:85,133-134)
+};
+
+struct HostBlas {
+  uint32_t model = 0;
+  std::vector<RefNode> nodes;       // reference layout
+  std::vector<uint32_t> prims;      // indices into HostScene::prims (post-build order)
+};
+
+struct HostPrim {
+  uint32_t kind, node, material, src;
+  F4 p[3];       // model space
+  F4 centroid;   // model space, (v0+v1+v2)*0.3333
+  F4 wp[3];      // world space = trs * p  (bit-identical to what Triangle::intersects recomputes)
+  F4 wcentroid, wmin, wmax;
+  F4 center;     // sphere
+  float radius;
+  PrimExt ext;
+};
+
+struct HostScene {
+  std::vector<Trs> local_trs, world_trs;
+  bool has_camera = false;
+  uint32_t camera_node = 0;
+  float camera_yfov = 0.0f;
+  std::vector<HostLight> lights;
+  std::vector<RaycaMaterial> materials;
+  std::vector<RaycaTexture> textures;
+  std::vector<RaycaImage> images;
+  std::vector<uint8_t> image_bytes;
+  std::vector<HostPrim> prims;      // flatten order
+  std::vector<HostBlas> blas;       // in TLAS blas_nodes order (post-build)
+  uint32_t triangle_count = 0, sphere_count = 0;
+
+  // device layout
+  std::vector<DevNode> dev_nodes;
+  uint32_t root_ref = 0;            // packed ref of the root
+  F4 root_min, root_max;            // root box (tested before anything else, blas.rs:136-139)
+  std::vector<uint32_t> prim_order; // slot -> flatten index
+  uint32_t max_depth = 0;           // inner nodes on the longest root-to-leaf path
+};
+
+// Returns RAYCA_OK or an error code with `err` filled.
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& out, std::string& err);
+
+}  // namespace rayca

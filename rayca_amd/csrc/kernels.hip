@@ -1,0 +1,717 @@
+// kernels.hip -- hand-written gfx950 kernels of the rayca hot path.
+//
+//   k_generation<..>  one persistent-wavefront kernel per ray generation:
+//                     generation 0 = camera rays (rayca-soft/src/scene.rs:117-150),
+//                     generation g = the g-th bounce of Pathtracer::trace_impl
+//                     (integrator/pathtracer.rs:68-106).  Each wave pulls batches of 64 rays from a
+//                     per-XCD work counter, traverses the BVH with a per-lane node stack in LDS
+//                     (TlasNode/BvhNode::intersects, bvh/tlas.rs:136-180, bvh/blas.rs:129-177),
+//                     intersects triangles (rayca-geometry/src/triangle.rs:84-159), shades the hit
+//                     (hit.rs, brdf/ggx.rs, sampler/nee.rs, sampler/cosine.rs) and compacts the
+//                     surviving rays of the next generation with __ballot/__popcll/__shfl.
+//   k_resolve         folds the per-depth records back in the reference's evaluation order,
+//                     accumulates samples, applies gamma and quantises (scene.rs:146-148).
+//   k_trace_rays      Tlas::intersects for caller-supplied rays (parity/debug entry).
+//
+// No MFMA anywhere: there is no dense contraction in this path.  Built with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+
+namespace rayca {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct DRay {
+  F4 o, d, rd;  // origin (w=1), direction (w=0), zero-safe reciprocal
+};
+struct DHit {
+  float t;
+  uint32_t prim;
+  float u, v;
+};
+
+__device__ __forceinline__ DRay make_ray(F4 origin, F4 dir) {  // Ray::new  ray.rs:63-72
+  DRay r;
+  r.rd = reciprocal(dir);
+  origin.w = 1.0f;
+  r.o = origin;
+  r.d = dir;
+  return r;
+}
+
+// ---- geometry --------------------------------------------------------------------------------
+// AABB::intersects  bvh/aabb.rs:74-93.  (a-o)*rdir goes through Point3::scale = fma(x, s, 0).
+__device__ __forceinline__ bool slab(float ax, float ay, float az, float bx, float by, float bz, const DRay& r, float& tmin_out) {
+  const float t1x = __fmaf_rn(ax - r.o.x, r.rd.x, 0.0f), t2x = __fmaf_rn(bx - r.o.x, r.rd.x, 0.0f);
+  const float t1y = __fmaf_rn(ay - r.o.y, r.rd.y, 0.0f), t2y = __fmaf_rn(by - r.o.y, r.rd.y, 0.0f);
+  const float t1z = __fmaf_rn(az - r.o.z, r.rd.z, 0.0f), t2z = __fmaf_rn(bz - r.o.z, r.rd.z, 0.0f);
+  const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), FLT_MAX));
+  const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), -FLT_MAX));
+  tmin_out = tmin;
+  return tmax >= tmin && tmax > 0.0f;
+}
+
+// Triangle::intersects  rayca-geometry/src/triangle.rs:84-159 on world-space vertices (identical
+// bits to `trs * vertex`, computed once on the host with the same operation sequence).
+__device__ __forceinline__ bool tri_test(F4 v0, F4 v1, F4 v2, const DRay& r, float& t_out, float& u_out, float& v_out) {
+  const F4 v0v1 = v1 - v0;
+  const F4 v0v2 = v2 - v0;
+  const F4 n = cross(v0v1, v0v2);
+  if (dot(r.d, n) > 0.0f) return false;  // back-face cull
+  const float denom = dot(n, n);
+  const float ndd = dot(n, r.d);
+  if (fabsf(ndd) < FLT_EPSILON) return false;
+  const float d = -dot(n, v0);
+  const float t = -(dot(n, to_vec(r.o)) + d) / ndd;
+  if (t < 0.0f) return false;
+  const F4 p = r.o + r.d * t;
+  F4 c = cross(v1 - v0, to_vec(p - v0));
+  if (dot(n, c) < 0.0f) return false;
+  c = cross(v2 - v1, to_vec(p - v1));
+  const float u = dot(n, c);
+  if (u < 0.0f) return false;
+  c = cross(v0 - v2, to_vec(p - v2));
+  const float v = dot(n, c);
+  if (v < 0.0f) return false;
+  t_out = t;
+  u_out = u / denom;
+  v_out = v / denom;
+  return true;
+}
+
+__device__ __forceinline__ void load_tri(const DevScene& sc, uint32_t i, F4& v0, F4& v1, F4& v2) {
+  if (sc.tri_soa) {
+    const float* p = sc.tris + i;
+    const size_t n = sc.prim_count;
+    v0 = vec3(p[0], p[n], p[2 * n]);
+    v1 = vec3(p[3 * n], p[4 * n], p[5 * n]);
+    v2 = vec3(p[6 * n], p[7 * n], p[8 * n]);
+  } else {
+    const float* p = sc.tris + 9ull * i;
+    v0 = vec3(p[0], p[1], p[2]);
+    v1 = vec3(p[3], p[4], p[5]);
+    v2 = vec3(p[6], p[7], p[8]);
+  }
+}
+
+struct LaneCounters {
+  uint32_t boxes = 0, tris = 0;
+};
+
+// Closest hit along `r` (Tlas::intersects).  stack = this lane's LDS column, entries `stride` apart.
+//   ORDERED    front-to-back descent, subtrees whose entry distance exceeds the current best are
+//              skipped.  The winner is the (t, primitive index) lexicographic minimum, which is what
+//              the reference's strict-< DFS returns (blas.rs:151,161,169).  The skip test carries a
+//              slack (relative 2^-10 plus sc.cull_abs) because a triangle's t and its box's slab
+//              entry are computed by different expressions and may disagree in the last bits.
+//   !ORDERED   visits exactly the boxes the reference visits (no culling).
+//   t_stop     any-hit early out: stop as soon as a hit with t < t_stop is found (shadow rays,
+//              "occluded iff closest depth < light distance", nee.rs:152-156).  FLT_MAX = never.
+template <bool ORDERED, bool STATS>
+__device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, uint32_t* stack, uint32_t stride, DHit& hit, LaneCounters& cnt) {
+  hit.t = INFINITY;
+  hit.prim = RAYCA_NONE;
+  hit.u = hit.v = 0.0f;
+  float tmin;
+  if (STATS) cnt.boxes++;
+  if (!slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], r, tmin)) return false;
+  uint32_t sp = 0;
+  uint32_t cur = sc.root_ref;
+  const bool any_hit = ORDERED && t_stop < FLT_MAX;
+  float limit = INFINITY;  // cull bound (ORDERED only)
+  if (any_hit) limit = t_stop + fabsf(t_stop) * 9.765625e-4f + sc.cull_abs;
+  for (;;) {
+    if (cur & kLeafFlag) {
+      const uint32_t first = cur & kLeafFirstMask;
+      const uint32_t count = ((cur >> 25) & 63u) + 1u;
+      for (uint32_t i = first; i < first + count; ++i) {
+        F4 v0, v1, v2;
+        load_tri(sc, i, v0, v1, v2);
+        if (STATS) cnt.tris++;
+        float t, u, v;
+        if (tri_test(v0, v1, v2, r, t, u, v)) {
+          if (t < hit.t || (t == hit.t && i < hit.prim)) {
+            hit.t = t;
+            hit.prim = i;
+            hit.u = u;
+            hit.v = v;
+            if (ORDERED) {
+              const float b = fminf(t, t_stop);
+              limit = b + fabsf(b) * 9.765625e-4f + sc.cull_abs;
+            }
+          }
+        }
+      }
+      if (any_hit && hit.t < t_stop) return true;
+      if (sp == 0) break;
+      cur = stack[(--sp) * stride];
+      continue;
+    }
+    const float4* np = sc.nodes + 4ull * cur;
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+    float tl, tr;
+    bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
+    bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+    if (STATS) cnt.boxes += 2;
+    const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+    if (ORDERED) {
+      hl = hl && tl <= limit;
+      hr = hr && tr <= limit;
+    }
+    if (hl && hr) {
+      const bool left_first = !ORDERED || tl <= tr;
+      stack[(sp++) * stride] = left_first ? rref : lref;
+      cur = left_first ? lref : rref;
+    } else if (hl) {
+      cur = lref;
+    } else if (hr) {
+      cur = rref;
+    } else {
+      if (sp == 0) break;
+      cur = stack[(--sp) * stride];
+    }
+  }
+  return hit.prim != RAYCA_NONE;
+}
+
+// ---- surface data (HitInfo, rayca-soft/src/hit.rs) ---------------------------------------------
+__device__ __forceinline__ Color load_color(const float* c) { return Color{c[0], c[1], c[2], c[3]}; }
+__device__ __forceinline__ F4 load_vec3(const float* c) { return vec3(c[0], c[1], c[2]); }
+
+__device__ __forceinline__ uint32_t f32_as_u32_sat(float v) {  // Rust `as u32`
+  if (!(v == v) || v <= 0.0f) return 0u;
+  if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+  return (uint32_t)v;
+}
+// Sampler::sample  rayca-model/src/sampler.rs:11-30 (nearest, wrap)
+__device__ Color sample_texture(const DevScene& sc, uint32_t tex, F2 uv) {
+  const DevTexture t = sc.textures[tex];
+  const float fx = (uv.x - floorf(uv.x) + 1.0f) * (float)t.width;
+  const float fy = (uv.y - floorf(uv.y) + 1.0f) * (float)t.height;
+  const uint32_t x = f32_as_u32_sat(fx) % t.width, y = f32_as_u32_sat(fy) % t.height;
+  const size_t idx = (size_t)y * t.width + x;
+  const uint8_t* base = sc.image_bytes + t.byte_offset;
+  if (t.color_type == RAYCA_COLOR_RGBA32F) {
+    const float* f = reinterpret_cast<const float*>(base) + idx * 4;
+    return Color{f[0] / 255.0f, f[1] / 255.0f, f[2] / 255.0f, f[3] / 255.0f};
+  }
+  if (t.color_type == RAYCA_COLOR_RGBA8) {
+    const uint8_t* p = base + idx * 4;
+    return Color{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f};
+  }
+  const uint8_t* p = base + idx * 3;
+  return Color{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 255.0f / 255.0f};
+}
+
+struct Surface {
+  const PrimExt* e;
+  DevMaterial m;
+  F4 point, view;  // hit point, -ray.dir
+  float bu, bv;    // barycentrics (u -> vertex 0, v -> vertex 1, 1-u-v -> vertex 2; bvh/triangle.rs:34-38)
+  F2 uv;
+  Color geom_color;
+  Color color;     // get_color: geometry colour x material colour
+  F4 normal;
+  F4 ray_dir;
+};
+
+__device__ __forceinline__ bool tex_valid(const DevScene& sc, uint32_t t) { return t != RAYCA_NONE && t < sc.texture_count; }
+
+__device__ __forceinline__ Color pbr_color(const DevScene& sc, const DevMaterial& m, F2 uv) {  // pbr.rs:94-102
+  const Color c = load_color(m.color);
+  if (tex_valid(sc, m.albedo_texture)) return c * sample_texture(sc, m.albedo_texture, uv);
+  return c;
+}
+__device__ __forceinline__ void pbr_metallic_roughness(const DevScene& sc, const DevMaterial& m, F2 uv, float& metallic, float& roughness) {
+  if (tex_valid(sc, m.metallic_roughness_texture)) {  // pbr.rs:125-137: (b, r)
+    const Color c = sample_texture(sc, m.metallic_roughness_texture, uv);
+    metallic = c.b;
+    roughness = c.r;
+  } else {
+    metallic = m.metallic_factor;
+    roughness = m.roughness_factor;
+  }
+}
+__device__ __forceinline__ DevMaterial default_material() {  // Material::DEFAULT -> PbrMaterial::WHITE
+  DevMaterial m{};
+  m.color[0] = m.color[1] = m.color[2] = m.color[3] = 1.0f;
+  m.ambient[3] = m.emission[3] = m.diffuse[3] = m.specular[3] = 1.0f;
+  m.kind = RAYCA_MATERIAL_PBR;
+  m.albedo_texture = m.normal_texture = m.metallic_roughness_texture = RAYCA_NONE;
+  m.metallic_factor = 0.0f;
+  m.roughness_factor = 1.0f;
+  return m;
+}
+
+__device__ __forceinline__ F4 interp3(const float (*a)[3], float bu, float bv) {
+  const float w2 = 1.0f - bu - bv;
+  return (load_vec3(a[2]) * w2 + load_vec3(a[0]) * bu) + load_vec3(a[1]) * bv;
+}
+
+// colour-only part (all Flat needs): primitive.rs:142-148
+__device__ __forceinline__ void surface_color(const DevScene& sc, Surface& s) {
+  const PrimExt& e = *s.e;
+  const float w2 = 1.0f - s.bu - s.bv;
+  s.geom_color = (load_color(e.color[2]) * w2 + load_color(e.color[0]) * s.bu) + load_color(e.color[1]) * s.bv;
+  s.uv = F2{(e.uv[2][0] * w2 + e.uv[0][0] * s.bu) + e.uv[1][0] * s.bv, (e.uv[2][1] * w2 + e.uv[0][1] * s.bu) + e.uv[1][1] * s.bv};
+  s.m = (e.material != RAYCA_NONE && e.material < sc.material_count) ? sc.materials[e.material] : default_material();
+  Color mc;
+  if (s.m.kind == RAYCA_MATERIAL_PBR) mc = pbr_color(sc, s.m, s.uv);
+  else if (s.m.kind == RAYCA_MATERIAL_PHONG) mc = load_color(s.m.ambient) + load_color(s.m.emission);
+  else mc = load_color(s.m.diffuse);
+  s.color = s.geom_color * mc;
+}
+// normal: primitive.rs:172-182 -> material/mod.rs:125-139 -> pbr.rs:104-123
+__device__ __forceinline__ void surface_normal(const DevScene& sc, Surface& s) {
+  const PrimExt& e = *s.e;
+  const F4 normal = normalized(interp3(e.normal, s.bu, s.bv));
+  if (s.m.kind == RAYCA_MATERIAL_PBR && tex_valid(sc, s.m.normal_texture)) {
+    const F4 tangent = normalized(interp3(e.tangent, s.bu, s.bv));
+    const F4 bitangent = normalized(interp3(e.bitangent, s.bu, s.bv));
+    F4 sn = premultiplied(sample_texture(sc, s.m.normal_texture, s.uv));
+    sn = sn * 2.0f - f4(1.0f, 1.0f, 1.0f, 1.0f);
+    s.normal = normalized(mat3_apply(mat3_tbn(tangent, bitangent, normal), sn));
+  } else {
+    s.normal = normal;
+  }
+}
+__device__ __forceinline__ Color surf_diffuse(const DevScene& sc, const Surface& s) {  // primitive.rs:150-155
+  const Color md = s.m.kind == RAYCA_MATERIAL_PBR ? pbr_color(sc, s.m, s.uv) : load_color(s.m.diffuse);
+  return s.geom_color * md;
+}
+__device__ __forceinline__ Color surf_specular(const DevScene& sc, const Surface& s) {  // material/mod.rs:141-151
+  if (s.m.kind == RAYCA_MATERIAL_PBR) {
+    float me, ro;
+    pbr_metallic_roughness(sc, s.m, s.uv, me, ro);
+    return me * pbr_color(sc, s.m, s.uv);
+  }
+  return load_color(s.m.specular);
+}
+__device__ __forceinline__ float surf_roughness(const DevScene& sc, const Surface& s) {  // material/mod.rs:173-185
+  if (s.m.kind == RAYCA_MATERIAL_PHONG) return clampf(sqrtf(2.0f / (s.m.shininess + 2.0f)), 0.0f, 1.0f);
+  if (s.m.kind == RAYCA_MATERIAL_PBR) {
+    float me, ro;
+    pbr_metallic_roughness(sc, s.m, s.uv, me, ro);
+    return ro;
+  }
+  return s.m.roughness_factor;
+}
+
+// ---- BRDFs: brdf/ggx.rs:58-129, brdf/lambertian.rs:7-16 -----------------------------------------
+__device__ __forceinline__ float ggx_d(float a, F4 h, F4 n) {
+  const float a2 = a * a;
+  const float cos_theta = clampf(dot(h, n), 0.0f, 1.0f);
+  const float theta = acosf(cos_theta);
+  const float denominator = powf(cos_theta, 4.0f) * powf(a2 + powf(tanf(theta), 2.0f), 2.0f);
+  if (denominator == 0.0f) return 0.0f;
+  return a2 * kFrac1Pi / denominator;
+}
+__device__ __forceinline__ float ggx_g1(float a, F4 omega, F4 n) {
+  const float cos_theta = dot(omega, n);
+  if (cos_theta <= 0.0f) return 0.0f;
+  const float theta = acosf(cos_theta);
+  return 2.0f / (1.0f + sqrtf(1.0f + a * a * powf(tanf(theta), 2.0f)));
+}
+__device__ __forceinline__ Color ggx_f(Color ks, F4 omega_i, F4 h) {
+  const float oh = fabsf(dot(omega_i, h));
+  return ks + (white() - ks) * powf(1.0f - oh, 5.0f);
+}
+__device__ Color ggx_brdf(const DevScene& sc, const Surface& s, F4 omega_i) {
+  const Color kd = surf_diffuse(sc, s);
+  Color bsdf = black();
+  const F4 omega_o = s.view;
+  const F4 n = s.normal;
+  const float oin = clampf(dot(omega_i, n), 0.0f, 1.0f);
+  const float oon = clampf(dot(omega_o, n), 0.0f, 1.0f);
+  if (!(oin == 0.0f || oon == 0.0f)) {
+    const Color ks = surf_specular(sc, s);
+    const float a = surf_roughness(sc, s);
+    const F4 h = normalized(omega_i + omega_o);
+    const Color f = ggx_f(ks, omega_i, h);
+    const float g = ggx_g1(a, omega_i, n) * ggx_g1(a, omega_o, n);
+    const float d = ggx_d(a, h, n);
+    const float denominator = 4.0f * oin * oon;
+    bsdf = ((f * g) * d) / denominator;
+  }
+  return kd * kFrac1Pi + bsdf;
+}
+__device__ Color lambert_brdf(const DevScene& sc, const Surface& s, F4 omega_i) {
+  const Color lambertian = surf_diffuse(sc, s) * kFrac1Pi;
+  const float sh = s.m.shininess;
+  const F4 refl = normalized(reflect(s.ray_dir, s.normal));  // hit.rs:93-101
+  const Color specular = (((surf_specular(sc, s) * (sh + 2.0f)) * powf(dot(refl, omega_i), sh)) * kFrac1Pi) / 2.0f;
+  return lambertian + specular;
+}
+__device__ __forceinline__ Color surf_brdf(const DevScene& sc, const Surface& s, F4 omega_i) {  // hit.rs:220-227
+  return s.m.kind == RAYCA_MATERIAL_PHONG ? lambert_brdf(sc, s, omega_i) : ggx_brdf(sc, s, omega_i);
+}
+
+// ---- work distribution ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7u;
+}
+// Next 64-wide batch for this wave, or RAYCA_NONE.  The batch list is cut into 8 contiguous
+// partitions, one per XCD: waves drain their own XCD's partition first (neighbouring image tiles ->
+// the same L2), then steal from the others.  Placement only affects speed, never results.
+__device__ __forceinline__ uint32_t next_batch(uint32_t* heads, uint32_t total, uint32_t home, uint32_t& exhausted) {
+  while (exhausted < 8u) {
+    const uint32_t part = (home + exhausted) & 7u;
+    const uint32_t lo = (uint32_t)(((uint64_t)part * total) >> 3), hi = (uint32_t)(((uint64_t)(part + 1u) * total) >> 3);
+    uint32_t idx = 0;
+    if (__lane_id() == 0) idx = atomicAdd(&heads[part], 1u);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    if (idx < hi - lo) return lo + idx;
+    exhausted++;
+  }
+  return RAYCA_NONE;
+}
+
+struct PathBuffers {
+  float4* direct;   // [depth][npix] Color: direct lighting, or the terminal colour
+  float4* brdf;     // [depth][npix] Color: factor get_radiance applies to the child's radiance
+  uint32_t* state;  // [depth][npix] kVertex*
+  uint32_t npix;
+};
+
+__device__ __forceinline__ float4 as_f4(Color c) { return make_float4(c.r, c.g, c.b, c.a); }
+__device__ __forceinline__ Color as_color(float4 c) { return Color{c.x, c.y, c.z, c.w}; }
+
+// scene.rs:146-148: color /= spp; correct_gamma; RGBA8::from
+__device__ __forceinline__ void finalize_pixel(const FrameParams& fp, Color acc, uint32_t p, uint8_t* rgba8, float4* rgba32f) {
+  Color c = acc / (float)fp.spp;
+  if (fp.inv_gamma != 1.0f) {
+    c.r = powf(c.r, fp.inv_gamma);
+    c.g = powf(c.g, fp.inv_gamma);
+    c.b = powf(c.b, fp.inv_gamma);
+  }
+  if (rgba32f) rgba32f[p] = as_f4(c);
+  if (rgba8) {
+    const uint32_t packed = (uint32_t)quantize(c.r) | ((uint32_t)quantize(c.g) << 8) | ((uint32_t)quantize(c.b) << 16) | ((uint32_t)quantize(c.a) << 24);
+    reinterpret_cast<uint32_t*>(rgba8)[p] = packed;
+  }
+}
+
+// Camera ray of output pixel (x, packed row r): scene.rs:125-141 + trs.rs:275-284 + ray.rs:74-91
+__device__ __forceinline__ DRay camera_ray(const FrameParams& fp, uint32_t x, uint32_t y) {
+  const float xx = (2.0f * (((float)x + fp.sub_x) * fp.inv_width) - 1.0f) * fp.angle * fp.aspect;
+  const float yy = (1.0f - 2.0f * (((float)y + fp.sub_y) * fp.inv_height)) * fp.angle;
+  F4 dir = normalized(vec3(xx, yy, -1.0f));
+  F4 origin = point3(0.0f, 0.0f, 0.0f);
+  // Ray::scale
+  dir = dir * fp.camera.scale;
+  origin = point_scale(origin, fp.camera.scale);
+  // Ray::rotate
+  dir = rotate(dir, fp.camera.rotation);
+  origin = point_rotate(origin, fp.camera.rotation);
+  origin.w = 1.0f;
+  // Ray::translate
+  origin = origin + fp.camera.translation;
+  DRay r;
+  r.o = origin;
+  r.d = dir;
+  r.rd = reciprocal(dir);
+  return r;
+}
+
+// wave-aggregated append of the next generation's rays
+__device__ __forceinline__ void push_ray(bool has, const QueuedRay& qr, QueuedRay* out, uint32_t* out_count) {
+  const unsigned long long mask = __ballot(has);
+  if (mask == 0ull) return;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(out_count, (uint32_t)__popcll(mask));
+  base = __shfl(base, (int)leader);
+  if (has) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = qr;
+}
+
+constexpr int kModeFlat = 0, kModePath = 1;
+
+// NextEventEstimationSampler::get_direct_lighting  sampler/nee.rs:127-216
+template <bool ORDERED, bool STATS>
+__device__ Color nee_direct(const DevScene& sc, const FrameParams& fp, const Surface& s, F4 next_origin, uint32_t key, uint32_t& dim,
+                            uint32_t* stack, uint32_t stride, LaneCounters& cnt, uint32_t& shadow_rays) {
+  Color ret = black();
+  for (uint32_t li = 0; li < sc.light_count; ++li) {
+    const DevLight L = sc.lights[li];
+    for (uint32_t k = 0; k < fp.light_samples; ++k) {
+      Color x = black();
+      if (L.kind == RAYCA_LIGHT_POINT) {  // get_point_light_sample  nee.rs:127-166
+        const F4 x1 = f4(L.position[0], L.position[1], L.position[2], L.position[3]);
+        const F4 x_to_x1 = as_vec(x1 - s.point);
+        const float dist = length(x_to_x1);
+        const F4 omega = normalized(x_to_x1);
+        const DRay sr = make_ray(next_origin, omega);
+        DHit sh;
+        shadow_rays++;
+        // occluded iff the closest hit is nearer than the light  <=>  any hit with t < dist
+        const bool occluded = trace<ORDERED, STATS>(sc, sr, dist, stack, stride, sh, cnt) && sh.t < dist;
+        if (!occluded) {
+          // PointLight::get_intensity / get_fallof  light/point.rs:37-49
+          const F4 dvec = to_vec(s.point) - as_vec(x1 - f4(0, 0, 0, 1.0f));
+          const float r2 = norm2(dvec);
+          const float rr = sqrtf(r2);
+          const float fallof = hsum(f4(L.attenuation[0], L.attenuation[1], L.attenuation[2], 0.0f) * f4(1.0f, rr, r2, 0.0f));
+          const Color le = (L.intensity * load_color(L.color)) / fallof;
+          const Color brdf = surf_brdf(sc, s, omega);
+          const float r_squared = norm2(x_to_x1);
+          const float d_omega = 1.0f / r_squared;
+          const float n_dot_omega = clampf(dot(s.normal, omega), 0.0f, 1.0f);
+          x = ((le * brdf) * n_dot_omega) * d_omega;
+        }
+      } else if (L.kind == RAYCA_LIGHT_QUAD) {  // get_quad_light_sample  nee.rs:72-125
+        const F4 ab = f4(L.ab[0], L.ab[1], L.ab[2], 0.0f), ac = f4(L.ac[0], L.ac[1], L.ac[2], 0.0f);
+        const float sc_f = (float)fp.strate_count;
+        const float u1 = rng_f32(key, dim++) / sc_f;
+        const float u2 = rng_f32(key, dim++) / sc_f;
+        const F4 a = f4(L.position[0], L.position[1], L.position[2], L.position[3]);
+        F4 x1 = (a + u1 * ab) + u2 * ac;  // quad.rs:112-135
+        if (fp.light_stratify) {
+          const float i1 = (float)(k % fp.strate_count), i2 = (float)(k / fp.strate_count);
+          x1 = x1 + ((ab / sc_f) * i1 + (ac / sc_f) * i2);
+        }
+        const F4 x_to_x1 = as_vec(x1 - s.point);
+        const F4 omega = normalized(x_to_x1);
+        const DRay sr = make_ray(next_origin, omega);
+        DHit sh;
+        shadow_rays++;
+        if (trace<ORDERED, STATS>(sc, sr, FLT_MAX, stack, stride, sh, cnt)) {
+          const PrimExt& he = sc.ext[sh.prim];
+          const bool emissive = he.material != RAYCA_NONE && he.material < sc.material_count && sc.materials[he.material].emissive;
+          if (emissive) {
+            const Color le = L.intensity * load_color(L.color);
+            const Color brdf = surf_brdf(sc, s, omega);
+            const float r_squared = norm2(x_to_x1);
+            const float d_omega = dot(f4(L.normal[0], L.normal[1], L.normal[2], 0.0f), omega) / r_squared;
+            const float n_dot_omega = clampf(dot(s.normal, omega), 0.0f, 1.0f);
+            x = (((le * L.area) * brdf) * n_dot_omega) * d_omega;
+          }
+        }
+      }
+      ret = ret + x;
+    }
+  }
+  return ret;
+}
+
+template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
+                                                       const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
+                                                       PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
+                                                       TraceCounters* counters) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  const uint32_t stride = kBlock;
+  const uint32_t lane = __lane_id();
+  const uint32_t home = xcc_id();
+  uint32_t exhausted = 0;
+  const uint32_t total = GEN0 ? fp.tile_count : (*in_count + 63u) / 64u;
+  LaneCounters cnt;
+  uint32_t n_shaded = 0, n_shadow = 0, n_bounce = 0;
+
+  for (;;) {
+    const uint32_t batch = next_batch(heads, total, home, exhausted);
+    if (batch == RAYCA_NONE) break;
+    bool active;
+    uint32_t p = 0, key = 0;
+    DRay ray;
+    if (GEN0) {
+      const uint32_t ty = batch / fp.tiles_x, tx = batch - ty * fp.tiles_x;
+      const uint32_t x = tx * 8u + (lane & 7u), r = ty * 8u + (lane >> 3);
+      active = x < fp.width && r < fp.rows;
+      const uint32_t y = ((r / fp.band) * fp.parts + fp.part) * fp.band + (r % fp.band);
+      p = r * fp.width + x;
+      if (active) {
+        ray = camera_ray(fp, x, y);
+        key = rng_root(fp.seed, y * fp.width + x, fp.sample);
+      }
+    } else {
+      const uint32_t i = batch * 64u + lane;
+      active = i < *in_count;
+      if (active) {
+        const QueuedRay q = in_rays[i];
+        ray = make_ray(point3(q.ox, q.oy, q.oz), vec3(q.dx, q.dy, q.dz));
+        p = q.pixel;
+        key = q.key;
+      }
+    }
+    bool want_bounce = false;
+    QueuedRay next{};
+    if (active) {
+      DHit hit;
+      const bool found = trace<ORDERED, STATS>(sc, ray, FLT_MAX, stack, stride, hit, cnt);
+      const size_t slot = (size_t)depth * pb.npix + p;
+      if (!found) {
+        if (FUSED) finalize_pixel(fp, black() + black(), p, rgba8, rgba32f);  // unwrap_or(BLACK), color += it
+        else pb.state[slot] = kVertexNone;
+      } else {
+        n_shaded++;
+        Surface s;
+        s.e = &sc.ext[hit.prim];
+        s.bu = hit.u;
+        s.bv = hit.v;
+        s.point = ray.o + ray.d * hit.t;
+        s.view = -ray.d;
+        s.ray_dir = ray.d;
+        surface_color(sc, s);
+        if (MODE == kModeFlat) {  // Flat::trace  integrator/flat.rs:16-28
+          if (FUSED) finalize_pixel(fp, black() + s.color, p, rgba8, rgba32f);
+          else {
+            pb.direct[slot] = as_f4(s.color);
+            pb.state[slot] = kVertexEmissive;
+          }
+        } else {  // Pathtracer::trace_impl  integrator/pathtracer.rs:68-106
+          const bool collect_emissive = GEN0 ? true : (fp.direct_sampler == RAYCA_SAMPLER_NONE);
+          if (collect_emissive && s.m.emissive) {
+            pb.direct[slot] = as_f4(s.color);
+            pb.state[slot] = kVertexEmissive;
+          } else {
+            surface_normal(sc, s);
+            const F4 next_origin = s.point + s.normal * kRayBias;  // hit.rs:164-171
+            uint32_t dim = 0;
+            Color direct = black();
+            if (fp.direct_sampler == RAYCA_SAMPLER_NEE) direct = nee_direct<ORDERED, STATS>(sc, fp, s, next_origin, key, dim, stack, stride, cnt, n_shadow);
+            const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
+            pb.direct[slot] = as_f4(direct);
+            if (depth < limit) {
+              // CosineSampler::get_random_dir  sampler/cosine.rs:65-88
+              const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
+              float theta, omega_a = 2.0f * kPi * e2;
+              if (fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE) theta = acosf(e1);  // hemisphere.rs:17-40
+              else theta = acosf(sqrtf(e1));
+              const F4 sdir = vec3(cosf(omega_a) * sinf(theta), sinf(omega_a) * sinf(theta), cosf(theta));
+              const F4 w = s.normal;
+              const F4 a = close(w, vec3(0, 1, 0)) ? vec3(1, 0, 0) : vec3(0, 1, 0);
+              const F4 u = normalized(cross(a, w));
+              F4 v = cross(w, u);
+              if (fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE) v = normalized(v);
+              const F4 omega_i = (sdir.x * u + sdir.y * v) + sdir.z * w;
+              const Color brdf = surf_brdf(sc, s, omega_i);
+              // the factor SoftSampler::get_radiance applies to the incoming radiance, evaluated in its
+              // order up to the point where the child's result enters: cosine.rs:90-99 `PI * brdf`,
+              // hemisphere.rs:42-52 `2.0 * PI * brdf * cosine_law`
+              Color factor;
+              if (fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE) factor = ((2.0f * kPi) * brdf) * clampf(dot(s.normal, omega_i), 0.0f, 1.0f);
+              else factor = kPi * brdf;
+              pb.brdf[slot] = as_f4(factor);
+              pb.state[slot] = kVertexLit;
+              if (depth + 1u < fp.max_depth) {
+                want_bounce = true;
+                next.ox = next_origin.x; next.oy = next_origin.y; next.oz = next_origin.z;
+                next.dx = omega_i.x; next.dy = omega_i.y; next.dz = omega_i.z;
+                next.pixel = p;
+                next.key = rng_child(key, 0u);
+                n_bounce++;
+              }
+            } else {
+              pb.state[slot] = kVertexLitNoIndirect;
+            }
+          }
+        }
+      }
+    }
+    if (MODE == kModePath) push_ray(want_bounce, next, out_rays, out_count);
+  }
+  if (STATS) {
+    // wave reduction, then one atomic per wave and counter
+    unsigned long long b = cnt.boxes, t = cnt.tris, sh = n_shaded;
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off);
+      t += __shfl_down(t, off);
+      sh += __shfl_down(sh, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&counters->boxes, b);
+      atomicAdd(&counters->tris, t);
+      atomicAdd(&counters->shaded, sh);
+    }
+  }
+  {
+    unsigned long long s2 = n_shadow, b2 = n_bounce;
+    for (int off = 32; off > 0; off >>= 1) {
+      s2 += __shfl_down(s2, off);
+      b2 += __shfl_down(b2, off);
+    }
+    if (lane == 0 && (s2 | b2)) {
+      atomicAdd(&counters->shadow, s2);
+      atomicAdd(&counters->bounce, b2);
+    }
+  }
+}
+
+// Fold the per-depth records in the reference's order (pathtracer.rs:23-66,94-105):
+//   L_g = direct_g + (BLACK + (BLACK + (factor_g * L_{g+1}) * weight) / light_samples)
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers pb, uint32_t depths, float4* accum, uint8_t* rgba8, float4* rgba32f) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pb.npix) return;
+  bool some = false;
+  Color L = black();
+  for (int g = (int)depths - 1; g >= 0; --g) {
+    const size_t slot = (size_t)g * pb.npix + p;
+    const uint32_t st = pb.state[slot];
+    if (st == kVertexNone) {
+      some = false;
+    } else if (st == kVertexEmissive) {
+      some = true;
+      L = as_color(pb.direct[slot]);
+    } else {
+      const Color direct = as_color(pb.direct[slot]);
+      Color indirect = black();
+      if (st == kVertexLit) {
+        Color li = black();
+        if (some) {
+          const Color factor = as_color(pb.brdf[slot]);
+          const Color x = (factor * L) * 1.0f;  // ... * indirect_sample * weight (weight = 1 without roulette)
+          li = li + x;
+        }
+        indirect = indirect + li / (float)fp.light_samples;
+      }
+      L = direct + indirect;
+      some = true;
+    }
+  }
+  const Color c = some ? L : black();
+  const Color prev = fp.sample == 0 ? black() : as_color(accum[p]);
+  const Color acc = prev + c;
+  if (fp.sample + 1u == fp.spp) finalize_pixel(fp, acc, p, rgba8, rgba32f);
+  else accum[p] = as_f4(acc);
+}
+
+template <bool ORDERED, bool STATS>
+__global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
+                                                       TraceCounters* counters) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  LaneCounters cnt;
+  if (i < count) {
+    const float* r = rays + 6ull * i;
+    const DRay ray = make_ray(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
+    DHit hit;
+    const bool found = trace<ORDERED, STATS>(sc, ray, FLT_MAX, stack, kBlock, hit, cnt);
+    t_out[i] = found ? hit.t : FLT_MAX;
+    prim_out[i] = found ? hit.prim : RAYCA_NONE;
+    uv_out[2 * i] = found ? hit.u : 0.0f;
+    uv_out[2 * i + 1] = found ? hit.v : 0.0f;
+  }
+  if (STATS) {
+    unsigned long long b = cnt.boxes, t = cnt.tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off);
+      t += __shfl_down(t, off);
+    }
+    if (__lane_id() == 0) {
+      atomicAdd(&counters->boxes, b);
+      atomicAdd(&counters->tris, t);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace rayca
+
+#include "api.inc"
