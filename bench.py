@@ -1,0 +1,201 @@
+"""bench.py -- Mrays/s and ms/frame of the rayca hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload atrium|soup|cornell|box]
+
+A "step" is one frame: every rank renders its rows of the frame with the HIP kernels (scene and BVH
+already resident in HBM) and rank 0 receives the gathered RGBA8 frame (one RCCL gather per frame,
+N > 1 only).  Default workload = the configuration BASELINE.json's metric is quoted on:
+1920x1080, primary + 1 shadow ray per hit (Pathtracer max_depth=1, NEE, one point light), 1 spp, on
+the ~272k-triangle procedural atrium -- a STAND-IN for Sponza, which is not available offline.
+
+One JSON line on rank 0:
+  value      whole-job Mrays/s = rays traced by all ranks in K steps / max-over-ranks wall time
+  roofline   dominant kernel k_generation (generation 0: camera rays + traversal + shading + shadow
+             rays): algorithmic bytes per launch (32 B per box test + 36 B per triangle test + 272 B
+             per shaded hit + 4 B per pixel, counted by the instrumented variant of the same kernel)
+             / mean launch duration from HIP events on the launch stream, against 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (port of the reference algorithm, per-test vertex transforms, all host
+             cores) on an evenly spaced subset of the same frame's rows; rank 0, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+
+def workload_config(name):
+    from rayca_amd import Config, IntegratorStrategy
+    if name == "atrium":
+        return dict(label="sponza-STAND-IN procedural atrium 271,568 tris, 1920x1080, primary + 1 shadow ray (Pathtracer max_depth=1, NEE, 1 point light), 1 spp",
+                    width=1920, height=1080, cfg=Config(max_depth=1))
+    if name == "soup":
+        return dict(label="synthetic soup 1,048,576 random tris (seed 0x5EED0001), 4096x4096, primary rays only (Flat), 1 spp",
+                    width=4096, height=4096, cfg=Config(integrator=IntegratorStrategy.Flat))
+    if name == "cornell":
+        return dict(label="cornell-style room 36 tris, 1920x1080, primary rays only (Flat), 1 spp",
+                    width=1920, height=1080, cfg=Config(integrator=IntegratorStrategy.Flat))
+    if name == "box":
+        return dict(label="Khronos Box glTF 12 tris + default model, 256x256, Pathtracer max_depth=1", width=256, height=256,
+                    cfg=Config(max_depth=1))
+    raise SystemExit(f"unknown workload {name}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="atrium")
+    ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--builder", default="sah", choices=["sah", "reference"],
+                    help="sah: SAH tree with empty-seeded candidate boxes (default); reference: the reference's tree, quirks included")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+    from rayca_amd import DeviceScene, abi, flatten, scenes
+    from rayca_amd.distributed import gather_frame, rows_of, tile_of
+
+    wl = workload_config(args.workload)
+    cfg, W, H = wl["cfg"], wl["width"], wl["height"]
+    scene = scenes.WORKLOADS[args.workload]["scene"]()
+    desc = flatten(scene)
+    builder = abi.BUILDER_SAH if args.builder == "sah" else abi.BUILDER_REFERENCE
+    ds = DeviceScene(desc, cfg, device=local_rank, builder=builder)
+    info = ds.info()
+    tile = tile_of(rank, world, args.band_rows)
+    my_rows = int(rows_of(tile, H).numel())
+    out = torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(dev)  # render kernels and the frame gather share this stream
+
+    def step(want_stats=False):
+        with torch.cuda.stream(stream):
+            st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=want_stats)
+            frame = gather_frame(out, H, args.band_rows) if world > 1 else out
+        return st, frame
+
+    # instrumented run: rays + algorithmic bytes of this rank's launch (not timed)
+    counted = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True, collect_stats=True)
+    rays_rank = counted["rays_primary"] + counted["rays_shadow"] + counted["rays_bounce"]
+    algo_bytes = 32 * counted["boxes_tested"] + 36 * counted["triangles_tested"] + 272 * counted["hits_shaded"] + 4 * my_rows * W
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, frame = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # kernel durations with HIP events on the launch stream (separate loop: the events force a sync per step)
+    kms, tms = [], []
+    for _ in range(max(3, min(args.steps, 20))):
+        st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
+        kms.append(st["kernel_ms"])
+        tms.append(st["trace_kernel_ms"] / max(st["trace_kernel_launches"], 1))
+    trace_ms = float(np.mean(tms))
+
+    t = torch.tensor([elapsed, float(rays_rank), float(algo_bytes), trace_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, rays_total = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, rays_total = elapsed, float(rays_rank)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    mrays = rays_total * args.steps / elapsed_max / 1e6
+    achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Mrays/sec (primary+shadow), 1920x1080 Sponza 1spp" if args.workload == "atrium" else f"Mrays/sec ({args.workload})",
+        "value": round(mrays, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wl["label"], "width": W, "height": H, "triangles": info["triangle_count"],
+                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1),
+                   "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
+                                   if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
+                   "rays_per_frame": int(rays_total), "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
+                   "frame_gather": "torch.distributed.gather (RCCL)" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "kernel": "k_generation (generation 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4),
+                     "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),
+                     "hits_shaded": int(counted["hits_shaded"]), "frame_kernel_ms": round(float(np.mean(kms)), 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(desc, cfg, W, H, args.cpu_seconds)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(desc, cfg, W, H, budget_s):
+    """The oracle (test infrastructure, a port of the reference algorithm) timed on this box's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    cores = os.cpu_count() or 1
+    orc = ol.OracleScene(desc, cfg, build=ol.BUILD_BINNED, xform=ol.XFORM_PER_TEST, threads=cores)
+    # probe: every `parts`-th row, starting sparse
+    parts = max(H // 8, 1)
+    _, _, st = orc.render(cfg, W, H, tile=(0, parts, 1), want_rgba8=False, want_f32=False)
+    rows_probe = st["rows_rendered"]
+    per_row = st["seconds"] / max(rows_probe, 1)
+    want_rows = int(min(H, max(rows_probe, budget_s / max(per_row, 1e-9))))
+    parts = max(H // want_rows, 1)
+    _, _, st = orc.render(cfg, W, H, tile=(0, parts, 1), want_rgba8=False, want_f32=False)
+    rays = st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
+    return {"value": round(rays / st["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"every {parts}-th row of the same {W}x{H} frame ({st['rows_rendered']} rows, {rays} rays, "
+                      f"{st['seconds']:.2f} s wall); per-test vertex transforms as in the reference; BVH build excluded "
+                      "like the reference's own timer (scene.rs:101,152)"}
+
+
+if __name__ == "__main__":
+    main()

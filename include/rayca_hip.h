@@ -250,7 +250,14 @@ enum {
   /* bit-for-bit restatement of Blas::set_primitives_recursive (bvh/blas.rs:261-316: SAH over 63
    * planes x 3 axes) and TlasNode::replace_models_recursive (bvh/tlas.rs:74-134), evaluated with an
    * exact binned sweep instead of 189 passes over the primitives */
-  RAYCA_BUILDER_REFERENCE = 0
+  RAYCA_BUILDER_REFERENCE = 0,
+  /* the same builder with ONE change: the candidate boxes of evaluate_sah start empty instead of at
+   * AABB::default() (= the origin, bvh/blas.rs:66-67 + bvh/aabb.rs:9-13).  The reference's seed
+   * makes every off-origin cluster unsplittable (leaves of 10^2..10^4 triangles on Sponza-class
+   * scenes); without it the tree is a regular SAH tree.  Closest hits are unchanged: depth ties are
+   * still resolved by the reference's primitive order, which is computed as well and uploaded as a
+   * per-primitive rank. */
+  RAYCA_BUILDER_SAH = 1
 };
 enum {
   /* front-to-back, best-t culled traversal (default).  The closest hit is order independent
@@ -307,7 +314,7 @@ typedef struct RaycaSceneInfo {
   uint32_t sphere_count;
   uint32_t blas_count;
   uint32_t node_count;      /* device BVH nodes (64 B each: two child boxes) */
-  uint32_t max_depth;       /* deepest leaf of the device BVH */
+  uint32_t max_depth;       /* traversal stack entries per ray (LDS) the device BVH needs */
   uint32_t light_count;
   uint64_t device_bytes;    /* HBM resident for this scene */
   float build_ms;           /* host BVH build + upload */

@@ -36,6 +36,7 @@ struct DevScene {
   const float4* nodes;  // 4 x float4 per DevNode
   const float* tris;    // 9 floats per primitive slot (world-space v0,v1,v2)
   const PrimExt* ext;   // per primitive slot
+  const uint32_t* tie_rank;  // nullptr: ties go to the lower slot; else to the lower rank (RAYCA_BUILDER_SAH)
   const DevMaterial* materials;
   const DevLight* lights;
   const DevTexture* textures;

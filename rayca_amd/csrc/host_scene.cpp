@@ -94,6 +94,7 @@ struct BlasBuilder {
   std::vector<uint32_t>* order;  // indices into scene->prims, partitioned in place
   uint32_t max_depth;
   unsigned parallel_levels;
+  bool seed_origin;  // true: the reference's AABB::default() seed (blas.rs:66-67); false: empty boxes
 
   const HostPrim& prim(uint32_t slot) const { return scene->prims[(*order)[slot]]; }
 
@@ -148,7 +149,7 @@ struct BlasBuilder {
       }
       Box lbox[65], rbox[65];
       uint32_t lcnt[65], rcnt[65];
-      lbox[0] = origin_box();
+      lbox[0] = seed_origin ? origin_box() : empty_box();
       lcnt[0] = 0;
       for (int b = 0; b < 64; ++b) {
         lbox[b + 1] = lbox[b];
@@ -158,7 +159,7 @@ struct BlasBuilder {
           lbox[b + 1].b = vmax(lbox[b + 1].b, bins[b].b);
         }
       }
-      rbox[64] = origin_box();
+      rbox[64] = seed_origin ? origin_box() : empty_box();
       rcnt[64] = 0;
       for (int b = 63; b >= 0; --b) {
         rbox[b] = rbox[b + 1];
@@ -169,7 +170,13 @@ struct BlasBuilder {
         }
       }
       for (int i = 1; i < 64; ++i) {
-        float cost = (float)lcnt[i] * area(lbox[i]) + (float)rcnt[i] * area(rbox[i]);
+        float cost;
+        if (seed_origin) {
+          cost = (float)lcnt[i] * area(lbox[i]) + (float)rcnt[i] * area(rbox[i]);
+        } else {
+          if (lcnt[i] == 0 || rcnt[i] == 0) continue;  // not a split
+          cost = (float)lcnt[i] * area(lbox[i]) + (float)rcnt[i] * area(rbox[i]);
+        }
         if (!(cost > 0.0f)) cost = FLT_MAX;
         if (cost < best_cost) {
           best_cost = cost;
@@ -338,59 +345,80 @@ struct DevBuilder {
     std::memset(&s.dev_nodes.back(), 0, sizeof(DevNode));
     return (uint32_t)s.dev_nodes.size() - 1;
   }
+  // Every emit_* returns the packed child reference and reports, through `need`, how many stack
+  // entries a traversal of that subtree can have pending at once: an inner node pushes one child and
+  // descends into the other, so need = 1 + max(need(left), need(right)) -- except for the chain nodes
+  // below, whose two boxes are identical so the left (leaf) child is always taken first and the
+  // pushed entry is popped before the rest of the chain is entered.
   // a leaf range: one packed ref, or a chain of nodes re-testing the same box for > 64 primitives
-  uint32_t emit_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t depth) {
+  uint32_t emit_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t& need) {
     if (count <= kLeafMaxPrims) {
-      s.max_depth = std::max(s.max_depth, depth);
+      need = 0;
       return leaf_ref(first, count == 0 ? 1 : count);
     }
-    const uint32_t n = new_node();
-    put_box(s.dev_nodes[n], 0, box);
-    put_box(s.dev_nodes[n], 1, box);
-    s.dev_nodes[n].left = leaf_ref(first, kLeafMaxPrims);
-    s.max_depth = std::max(s.max_depth, depth + 1);
-    const uint32_t rest = emit_leaf(first + kLeafMaxPrims, count - kLeafMaxPrims, box, depth + 1);
-    s.dev_nodes[n].right = rest;
-    return n;
+    // iterative: chains can be thousands of nodes long with the reference's coarse leaves
+    const uint32_t head = new_node();
+    uint32_t cur = head;
+    for (;;) {
+      put_box(s.dev_nodes[cur], 0, box);
+      put_box(s.dev_nodes[cur], 1, box);
+      s.dev_nodes[cur].left = leaf_ref(first, kLeafMaxPrims);
+      first += kLeafMaxPrims;
+      count -= kLeafMaxPrims;
+      if (count <= kLeafMaxPrims) {
+        s.dev_nodes[cur].right = leaf_ref(first, count);
+        break;
+      }
+      const uint32_t nxt = new_node();
+      s.dev_nodes[cur].right = nxt;
+      cur = nxt;
+    }
+    need = 1;
+    return head;
   }
-  uint32_t emit_blas_node(const HostBlas& bl, uint32_t base, uint32_t ref_idx, uint32_t depth) {
-    // iterative descent would be needed for degenerate 255-deep trees only; recursion depth <= 255
+  uint32_t emit_blas_node(const HostBlas& bl, uint32_t base, uint32_t ref_idx, uint32_t& need) {
     const RefNode& rn = bl.nodes[ref_idx];
     const Box box{rn.a, rn.b};
-    if (rn.count != 0 || (ref_idx == 0 && bl.prims.empty())) return emit_leaf(base + rn.offset, rn.count, box, depth);
+    if (rn.count != 0 || (ref_idx == 0 && bl.prims.empty())) return emit_leaf(base + rn.offset, rn.count, box, need);
     const uint32_t n = new_node();
     const RefNode &l = bl.nodes[rn.offset], &r = bl.nodes[rn.offset + 1];
     put_box(s.dev_nodes[n], 0, Box{l.a, l.b});
     put_box(s.dev_nodes[n], 1, Box{r.a, r.b});
-    const uint32_t lr = emit_blas_node(bl, base, rn.offset, depth + 1);
+    uint32_t nl = 0, nr = 0;
+    const uint32_t lr = emit_blas_node(bl, base, rn.offset, nl);
     s.dev_nodes[n].left = lr;
-    const uint32_t rr = emit_blas_node(bl, base, rn.offset + 1, depth + 1);
+    const uint32_t rr = emit_blas_node(bl, base, rn.offset + 1, nr);
     s.dev_nodes[n].right = rr;
+    need = 1 + std::max(nl, nr);
     return n;
   }
   // TLAS leaf holding blas [offset, offset+count): BLAS roots tested one after the other
-  uint32_t emit_blas_chain(uint32_t offset, uint32_t count, const Box& leaf_box, uint32_t depth) {
-    if (count == 1) return emit_blas_node(s.blas[offset], blas_base[offset], 0, depth);
+  uint32_t emit_blas_chain(uint32_t offset, uint32_t count, const Box& leaf_box, uint32_t& need) {
+    if (count == 1) return emit_blas_node(s.blas[offset], blas_base[offset], 0, need);
     const uint32_t n = new_node();
     const RefNode& root = s.blas[offset].nodes[0];
     put_box(s.dev_nodes[n], 0, Box{root.a, root.b});
     put_box(s.dev_nodes[n], 1, leaf_box);
-    const uint32_t lr = emit_blas_node(s.blas[offset], blas_base[offset], 0, depth + 1);
+    uint32_t nl = 0, nr = 0;
+    const uint32_t lr = emit_blas_node(s.blas[offset], blas_base[offset], 0, nl);
     s.dev_nodes[n].left = lr;
-    const uint32_t rr = emit_blas_chain(offset + 1, count - 1, leaf_box, depth + 1);
+    const uint32_t rr = emit_blas_chain(offset + 1, count - 1, leaf_box, nr);
     s.dev_nodes[n].right = rr;
+    need = 1 + std::max(nl, nr);
     return n;
   }
-  uint32_t emit_tlas(const std::vector<TNode>& tn, int32_t idx, uint32_t depth) {
+  uint32_t emit_tlas(const std::vector<TNode>& tn, int32_t idx, uint32_t& need) {
     const TNode& t = tn[idx];
-    if (t.left < 0) return emit_blas_chain(t.offset, t.count, t.bounds, depth);
+    if (t.left < 0) return emit_blas_chain(t.offset, t.count, t.bounds, need);
     const uint32_t n = new_node();
     put_box(s.dev_nodes[n], 0, tn[t.left].bounds);
     put_box(s.dev_nodes[n], 1, tn[t.right].bounds);
-    const uint32_t lr = emit_tlas(tn, t.left, depth + 1);
+    uint32_t nl = 0, nr = 0;
+    const uint32_t lr = emit_tlas(tn, t.left, nl);
     s.dev_nodes[n].left = lr;
-    const uint32_t rr = emit_tlas(tn, t.right, depth + 1);
+    const uint32_t rr = emit_tlas(tn, t.right, nr);
     s.dev_nodes[n].right = rr;
+    need = 1 + std::max(nl, nr);
     return n;
   }
 };
@@ -429,7 +457,7 @@ void set_ext(PrimExt& e, int k, Color c, F4 n, F4 t, F4 b, F2 uv) {
 
 }  // namespace
 
-int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& s, std::string& err) {
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err) {
   if (d.abi_version != RAYCA_ABI_VERSION) { err = "abi version mismatch"; return RAYCA_ERR_BAD_ARG; }
   if (d.node_count && !d.nodes) { err = "nodes is null"; return RAYCA_ERR_BAD_ARG; }
   if (d.vertex_count && !d.positions) { err = "positions is null"; return RAYCA_ERR_BAD_ARG; }
@@ -601,15 +629,27 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& s, st
   unsigned par_levels = 0;
   while ((1u << par_levels) < hw) ++par_levels;
   std::vector<Box> blas_root(blas.size());
-  for (size_t m = 0; m < blas.size(); ++m) {
-    BlasBuilder bb{&s, &blas[m].prims, use_bvh ? 255u : 0u, par_levels + 1};
+  // reference order of every primitive inside its BLAS (needed by both builders: it is the tie rule)
+  std::vector<std::vector<uint32_t>> ref_prims(blas.size());
+  auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<RefNode>& nodes) {
+    BlasBuilder bb{&s, &order, use_bvh ? 255u : 0u, par_levels + 1, seed_origin};
     std::vector<BuildNode> arena(1);
     arena[0].offset = 0;
-    arena[0].count = (uint32_t)blas[m].prims.size();
+    arena[0].count = (uint32_t)order.size();
     arena[0].bounds = bb.range_bounds(0, arena[0].count);
     if (arena[0].count > 0) bb.split(arena, 0, 0);
-    to_reference_layout(arena, blas[m].nodes);
+    to_reference_layout(arena, nodes);
     blas_root[m] = arena[0].bounds;
+  };
+  for (size_t m = 0; m < blas.size(); ++m) {
+    if (builder == RAYCA_BUILDER_SAH) {
+      ref_prims[m] = blas[m].prims;
+      std::vector<RefNode> ref_nodes;
+      build_blas(m, true, ref_prims[m], ref_nodes);   // the reference's order, for ties only
+      build_blas(m, false, blas[m].prims, blas[m].nodes);
+    } else {
+      build_blas(m, true, blas[m].prims, blas[m].nodes);
+    }
   }
   std::vector<uint32_t> blas_order(blas.size());
   for (size_t i = 0; i < blas.size(); ++i) blas_order[i] = (uint32_t)i;
@@ -617,6 +657,13 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& s, st
   if (!blas.empty()) tlas_split(tn, 0, blas_order, blas_root, 0, (uint32_t)blas.size());
   // store BLASes in TLAS order so that a TLAS range [offset, offset+count) indexes s.blas directly
   s.blas.clear();
+  std::vector<uint32_t> ref_rank;  // flatten index -> slot in the reference's global order
+  if (builder == RAYCA_BUILDER_SAH) {
+    ref_rank.assign(s.prims.size(), 0);
+    uint32_t slot = 0;
+    for (uint32_t b : blas_order)
+      for (uint32_t pi : ref_prims[b]) ref_rank[pi] = slot++;
+  }
   for (uint32_t b : blas_order) s.blas.push_back(std::move(blas[b]));
 
   // ---- device layout ----------------------------------------------------------------------------
@@ -634,7 +681,14 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& s, st
     if (base > kLeafFirstMask) { err = "too many primitives for the packed leaf reference (max 33554431)"; return RAYCA_ERR_UNSUPPORTED; }
     s.root_min = tn[0].bounds.a;
     s.root_max = tn[0].bounds.b;
-    s.root_ref = db.emit_tlas(tn, 0, 0);
+    uint32_t need = 0;
+    s.root_ref = db.emit_tlas(tn, 0, need);
+    s.max_depth = need;
+    s.tie_rank.clear();
+    if (builder == RAYCA_BUILDER_SAH) {
+      s.tie_rank.resize(s.prim_order.size());
+      for (size_t slot = 0; slot < s.prim_order.size(); ++slot) s.tie_rank[slot] = ref_rank[s.prim_order[slot]];
+    }
   }
   return RAYCA_OK;
 }

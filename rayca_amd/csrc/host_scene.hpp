@@ -89,10 +89,11 @@ struct HostScene {
   uint32_t root_ref = 0;            // packed ref of the root
   F4 root_min, root_max;            // root box (tested before anything else, blas.rs:136-139)
   std::vector<uint32_t> prim_order; // slot -> flatten index
-  uint32_t max_depth = 0;           // inner nodes on the longest root-to-leaf path
+  uint32_t max_depth = 0;           // stack entries a traversal can have pending at once
+  std::vector<uint32_t> tie_rank;   // RAYCA_BUILDER_SAH only: slot -> position in the reference's order
 };
 
 // Returns RAYCA_OK or an error code with `err` filled.
-int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, HostScene& out, std::string& err);
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err);
 
 }  // namespace rayca

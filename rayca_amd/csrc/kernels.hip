@@ -96,6 +96,14 @@ __device__ __forceinline__ void load_tri(const DevScene& sc, uint32_t i, F4& v0,
   }
 }
 
+// exact depth tie: the primitive that comes first in the reference's order wins (strict `<` in a
+// left-to-right DFS, blas.rs:151,161,169)
+__device__ __forceinline__ bool tie_before(const DevScene& sc, uint32_t a, uint32_t b) {
+  if (b == RAYCA_NONE) return true;
+  if (sc.tie_rank) return sc.tie_rank[a] < sc.tie_rank[b];
+  return a < b;
+}
+
 struct LaneCounters {
   uint32_t boxes = 0, tris = 0;
 };
@@ -132,7 +140,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
         if (STATS) cnt.tris++;
         float t, u, v;
         if (tri_test(v0, v1, v2, r, t, u, v)) {
-          if (t < hit.t || (t == hit.t && i < hit.prim)) {
+          if (t < hit.t || (t == hit.t && tie_before(sc, i, hit.prim))) {
             hit.t = t;
             hit.prim = i;
             hit.u = u;

@@ -1,0 +1,306 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bars: hit records (t, primitive, u, v) and every Flat pixel are bit-exact (pure +,-,*,/,sqrt f32
+arithmetic in the reference's operation order); shaded pixels that go through acos/tan/pow
+(GGX, brdf/ggx.rs:58-83) may differ by the host-libm vs device-libm rounding of those functions:
+|gpu - oracle| <= 1e-4 per channel (BASELINE.json north_star) and <= 1 LSB after RGBA8 quantisation.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from rayca_amd import (Config, DeviceScene, Image, IntegratorStrategy, Light, Mesh, Model, Node, PbrMaterial,
+                       PhongMaterial, Primitive, SamplerStrategy, Scene, SoftRenderer, Texture, TriangleMesh, Trs, abi,
+                       flatten, scenes)
+from rayca_amd.lib import RaycaError
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4
+FLAT = Config(integrator=IntegratorStrategy.Flat)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def pair(desc, cfg=None, **okw):
+    return DeviceScene(desc, cfg or Config()), ol.OracleScene(desc, cfg or Config(), **okw)
+
+
+def assert_exact(gpu_f32, ora_f32):
+    assert np.array_equal(bits(gpu_f32), bits(ora_f32)), f"max abs diff {np.abs(gpu_f32 - ora_f32).max()}"
+
+
+def assert_close(gpu, ora, u8=None, ou8=None):
+    d = np.abs(gpu - ora)
+    assert d.max() <= TOL, f"max abs diff {d.max():.3e} at {np.unravel_index(d.argmax(), d.shape)}"
+    if u8 is not None:
+        assert np.abs(u8.astype(int) - ou8.astype(int)).max() <= 1
+
+
+@pytest.fixture(scope="module")
+def box(gpu):
+    return pair(flatten(scenes.box_scene()))
+
+
+@pytest.fixture(scope="module")
+def cornell(gpu):
+    return pair(flatten(scenes.cornell_scene()))
+
+
+def test_box_flat_is_bit_exact_and_matches_golden(box):
+    ds, orc = box
+    g = np.load(os.path.join(G, "box_256.npz"))
+    u8, f32, st = ds.render(FLAT, 256, 256)
+    ou8, of32, _ = orc.render(FLAT, 256, 256)
+    assert_exact(f32, of32)
+    assert_exact(f32, g["flat"])
+    assert np.array_equal(u8, ou8)
+    assert st["rays_primary"] == 65536 and st["kernel_launches"] == 1
+
+
+def test_box_pathtracer_depth1_within_tolerance(box):
+    ds, orc = box
+    g = np.load(os.path.join(G, "box_256.npz"))
+    cfg = Config(max_depth=1)
+    u8, f32, st = ds.render(cfg, 256, 256, collect_stats=True)
+    ou8, of32, ost = orc.render(cfg, 256, 256)
+    assert_close(f32, of32, u8, ou8)
+    assert_close(f32, g["pt1"])
+    assert np.array_equal(f32 == 0, of32 == 0)          # identical hit/miss/shadow decisions
+    assert st["rays_shadow"] == ost["rays_shadow"] == 2 * 7744 and st["hits_shaded"] == ost["hits_shaded"]
+
+
+def test_reference_style_draw_surface(gpu):
+    """Reads like rayca-soft/tests/gltf.rs:191-204: SoftRenderer::default().draw(&scene, &mut image)."""
+    image = Image(256, 256)
+    renderer = SoftRenderer()
+    scene = Scene()
+    scene.push_model(scenes.load_gltf(os.path.join(G, "box.gltf")))
+    scene.push_model(SoftRenderer.create_default_model())
+    renderer.draw(scene, image)
+    orc = ol.OracleScene(flatten(scene), Config())
+    ou8, _, _ = orc.render(Config(), 256, 256)
+    assert image.data[..., 3].min() == 255 and (image.data[..., 0] > 0).sum() > 5000
+    # default Config = Pathtracer depth 5 with random bounces: same counter-based RNG on both sides;
+    # a bounce ray can still split at a silhouette when acos/sin/cos differ in the last bit
+    diff = np.abs(image.data.astype(int) - ou8.astype(int)).max(-1)
+    assert (diff > 1).mean() < 0.01
+
+
+def test_triangle_scene_vertex_colour_interpolation(gpu):
+    # rayca-soft/tests/gltf.rs:48-84
+    ds, orc = pair(flatten(scenes.triangle_scene()))
+    _, f32, _ = ds.render(FLAT, 256, 256)
+    _, of32, _ = orc.render(FLAT, 256, 256)
+    assert_exact(f32, of32)
+    assert len(np.unique(f32[..., :3].reshape(-1, 3), axis=0)) > 1000  # a real gradient
+
+
+@pytest.mark.parametrize("name", ["box", "cornell", "soup1k"])
+def test_hit_records_bit_exact(gpu, name):
+    if name == "soup1k":
+        g = np.load(os.path.join(G, "soup1k_rays.npz"))
+        desc = flatten(scenes.soup_scene(1000, extent=0.12))
+    elif name == "box":
+        g = np.load(os.path.join(G, "box_256.npz"))
+        desc = flatten(scenes.box_scene())
+    else:
+        g = np.load(os.path.join(G, "cornell_128x72.npz"))
+        desc = flatten(scenes.cornell_scene())
+    ds, orc = pair(desc)
+    assert np.array_equal(ds.primitive_order(), orc.primitive_order())
+    for trav in (abi.TRAVERSAL_ORDERED, abi.TRAVERSAL_EXHAUSTIVE):
+        t, prim, uv, st = ds.trace_rays(g["rays"], traversal=trav, collect_stats=True)
+        ot, oprim, ouv, ost = orc.trace_rays(g["rays"])
+        assert np.array_equal(prim, oprim) and np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(uv), bits(ouv))
+        assert np.array_equal(prim, g["prim"]) and np.array_equal(bits(t), bits(g["t"]))
+        if trav == abi.TRAVERSAL_EXHAUSTIVE:
+            assert st["triangles_tested"] == ost["triangles_tested"]  # visits exactly the reference's leaves
+
+
+def test_cornell_1080p_flat_bit_exact(cornell):
+    """BASELINE configs[1]: Cornell-box-style scene, primary rays only, 1920x1080."""
+    ds, orc = cornell
+    u8, f32, st = ds.render(FLAT, 1920, 1080)
+    ou8, of32, _ = orc.render(FLAT, 1920, 1080)
+    assert_exact(f32, of32)
+    assert np.array_equal(u8, ou8)
+
+
+def test_cornell_depth1_and_bounces(cornell):
+    ds, orc = cornell
+    cfg = Config(max_depth=1)
+    u8, f32, _ = ds.render(cfg, 640, 360)
+    ou8, of32, _ = orc.render(cfg, 640, 360)
+    assert_close(f32, of32, u8, ou8)
+    # 4 bounces (default depth 5): every direction comes from acos/sin/cos, so a handful of paths may
+    # take another route; the bulk must still agree to tolerance and the frame means must match
+    cfg = Config()
+    _, f32, st = ds.render(cfg, 640, 360, collect_stats=True)
+    _, of32, ost = orc.render(cfg, 640, 360)
+    bad = (np.abs(f32 - of32).max(-1) > TOL).mean()
+    assert bad < 0.01, bad
+    assert abs(float(f32[..., :3].mean()) - float(of32[..., :3].mean())) < 2e-3 * float(of32[..., :3].mean() + 1e-6) + 1e-6
+    assert abs(st["rays_bounce"] - ost["rays_bounce"]) <= 0.001 * ost["rays_bounce"]
+
+
+def test_odd_sizes_and_zero_direction_quirk(box):
+    ds, orc = box
+    for (w, h) in ((65, 64), (33, 17), (1, 1), (127, 255)):
+        _, f32, _ = ds.render(FLAT, w, h)
+        _, of32, _ = orc.render(FLAT, w, h)
+        assert_exact(f32, of32)
+    _, f32, _ = ds.render(FLAT, 65, 64)
+    assert np.all(f32[:, 32, :3] == 0)   # centre column: dir.x == 0 -> misses every AABB
+
+
+def test_samples_per_pixel_and_gamma(box):
+    ds, orc = box
+    cfg = Config(integrator=IntegratorStrategy.Flat, samples_per_pixel=4, gamma=2.2)
+    u8, f32, _ = ds.render(cfg, 128, 128)
+    ou8, of32, _ = orc.render(cfg, 128, 128)
+    assert_close(f32, of32, u8, ou8)      # powf(1/gamma): device vs host libm
+    cfg = Config(integrator=IntegratorStrategy.Flat, samples_per_pixel=4)
+    _, f32, _ = ds.render(cfg, 128, 128)
+    _, of32, _ = orc.render(cfg, 128, 128)
+    assert_exact(f32, of32)               # gamma 1.0: stratified accumulation is exact
+    cfg = Config(max_depth=2, samples_per_pixel=2)
+    _, f32, _ = ds.render(cfg, 96, 96)
+    _, of32, _ = orc.render(cfg, 96, 96)
+    assert (np.abs(f32 - of32).max(-1) > TOL).mean() < 0.01
+
+
+def test_bvh_disabled_matches(gpu):
+    desc = flatten(scenes.cornell_scene())
+    cfg = Config(integrator=IntegratorStrategy.Flat, bvh=False)
+    ds, orc = pair(desc, cfg)
+    assert ds.info()["max_depth"] <= 1
+    _, f32, _ = ds.render(cfg, 320, 180)
+    _, of32, _ = orc.render(cfg, 320, 180)
+    assert_exact(f32, of32)
+
+
+def test_large_leaf_chains_soup(gpu):
+    """The reference's SAH (boxes seeded at the origin) leaves 100+ triangle leaves: exercises the
+    64-primitive leaf chunks and the ordered/exhaustive equivalence."""
+    desc = flatten(scenes.soup_scene(20000))
+    ds, orc = pair(desc, build=ol.BUILD_BINNED)
+    assert np.array_equal(ds.primitive_order(), orc.primitive_order())
+    _, a, _ = ds.render(FLAT, 512, 512)
+    _, b, _ = ds.render(FLAT, 512, 512, traversal=abi.TRAVERSAL_EXHAUSTIVE)
+    _, o, _ = orc.render(FLAT, 512, 512)
+    assert_exact(a, o)
+    assert_exact(b, o)
+
+
+def _textured_quad_scene():
+    model = Model()
+    rs = np.random.RandomState(5)
+    tex = rs.randint(0, 256, (8, 8, 4)).astype(np.uint8)
+    tex[..., 3] = 255
+    img = model.images.push(Image(8, 8, abi.COLOR_RGBA8, tex))
+    t = model.textures.push(Texture(image=img))
+    mat = model.materials.push(PbrMaterial(color=(0.9, 0.8, 0.7, 1.0), albedo=t, roughness_factor=0.8))
+    g = model.geometries.push(TriangleMesh.quad(uv_scale=(3.0, 2.0)))
+    p = model.primitives.push(Primitive(geometry=g, material=mat))
+    n = model.nodes.push(Node(mesh=model.meshes.push(Mesh(primitives=[p])), trs=Trs(scale=(3.0, 3.0, 1.0))))
+    model.root.children.append(n)
+    scene = Scene()
+    scene.push_model(model)
+    scene.push_model(SoftRenderer.create_default_model())
+    return scene
+
+
+def test_albedo_texture_nearest_wrap(gpu):
+    # Sampler::sample (rayca-model/src/sampler.rs:11-30) through PbrMaterial::get_color (pbr.rs:94-102)
+    ds, orc = pair(flatten(_textured_quad_scene()))
+    _, f32, _ = ds.render(FLAT, 200, 200)
+    _, of32, _ = orc.render(FLAT, 200, 200)
+    assert_exact(f32, of32)
+    assert len(np.unique((f32[..., :3] * 255).astype(int).reshape(-1, 3), axis=0)) > 30
+    cfg = Config(max_depth=1)
+    u8, f32, _ = ds.render(cfg, 200, 200)
+    ou8, of32, _ = orc.render(cfg, 200, 200)
+    assert_close(f32, of32, u8, ou8)
+
+
+def _quad_light_room():
+    """Phong room lit by an emissive quad light (the SDTF-style setup, light/quad.rs + nee.rs:72-125)."""
+    model = Model()
+    wall = model.materials.push(PhongMaterial(diffuse=(0.7, 0.7, 0.7, 1.0), specular=(0.1, 0.1, 0.1, 1.0), shininess=8.0))
+    emit = model.materials.push(PhongMaterial(emission=(1.0, 1.0, 1.0, 1.0)))
+    room = scenes._MeshBuilder()
+    X, Y, Z = np.array([2, 0, 0], np.float32), np.array([0, 2, 0], np.float32), np.array([0, 0, 2], np.float32)
+    room.grid((-1, 0, -1), Z, X, 1, 1)
+    room.grid((-1, 0, -1), X, Y, 1, 1)
+    room.grid((-1, 0, -1), Y, Z, 1, 1)
+    room.grid((1, 0, -1), Z, Y, 1, 1)
+    room.box((-0.4, 0, -0.4), (0.2, 0.7, 0.2))
+    g = model.geometries.push(room.mesh())
+    p = model.primitives.push(Primitive(geometry=g, material=wall))
+    model.root.children.append(model.nodes.push(Node(mesh=model.meshes.push(Mesh(primitives=[p])))))
+    lt = model.lights.push(Light.quad(ab=(0.6, 0.0, 0.0), ac=(0.0, 0.0, 0.6), color=(1, 1, 1, 1), material=emit, intensity=6.0))
+    # ab x ac = -y: the light faces down
+    model.root.children.append(model.nodes.push(Node(light=lt, trs=Trs(translation=(-0.3, 1.9, -0.3)))))
+    cam = model.cameras.push(scenes.Camera())
+    model.root.children.append(model.nodes.push(Node(camera=cam, trs=Trs(translation=(0.0, 1.0, 3.2)))))
+    scene = Scene()
+    scene.push_model(model)
+    return scene
+
+
+def test_quad_light_nee_with_phong_materials(gpu):
+    desc = flatten(_quad_light_room())
+    ds, orc = pair(desc)
+    cfg = Config(max_depth=1, light_samples=4, light_stratify=True, seed=3)
+    u8, f32, st = ds.render(cfg, 160, 120, collect_stats=True)
+    ou8, of32, ost = orc.render(cfg, 160, 120)
+    assert st["rays_shadow"] == ost["rays_shadow"] > 0
+    assert (np.abs(f32 - of32).max(-1) > TOL).mean() < 0.002   # powf(x, shininess) in the Phong lobe
+    assert float(f32[..., :3].max()) > 0.05                    # the light actually reaches the floor
+    _, f32, _ = ds.render(FLAT, 160, 120)
+    _, of32, _ = orc.render(FLAT, 160, 120)
+    assert_exact(f32, of32)                                    # emissive quad visible to primary rays
+
+
+def test_errors_mirror_the_reference_panics(gpu):
+    scene = Scene()
+    scene.push_model(scenes.load_gltf(os.path.join(G, "box.gltf")))
+    ds = DeviceScene(flatten(scene), Config())
+    with pytest.raises(RaycaError) as e:
+        ds.render(Config(), 8, 8)
+    assert e.value.code == abi.ERR_NO_CAMERA            # assert!(!camera_draw_infos.is_empty())  scene.rs:109
+    scene = Scene()
+    scene.push_model(SoftRenderer.create_default_model())
+    ds = DeviceScene(flatten(scene), Config())
+    with pytest.raises(RaycaError) as e:
+        ds.render(Config(), 8, 8)
+    assert e.value.code == abi.ERR_EMPTY_SCENE          # Tlas::intersects assert  tlas.rs:272
+    ds = DeviceScene(flatten(scenes.box_scene()), Config())
+    for bad in (Config(integrator=IntegratorStrategy.Raytracer), Config(russian_roulette=True),
+                Config(direct_sampler=SamplerStrategy.Mis), Config(light_samples=2)):
+        with pytest.raises(RaycaError) as e:
+            ds.render(bad, 8, 8)
+        assert e.value.code == abi.ERR_UNSUPPORTED       # fails loudly, never falls back to a CPU path
+    with pytest.raises(RaycaError) as e:
+        ds.render(Config(), 0, 8)
+    assert e.value.code == abi.ERR_BAD_ARG
+
+
+def test_tiles_reassemble_to_the_full_frame(cornell):
+    ds, _ = cornell
+    cfg = Config(max_depth=1)
+    h, w = 271, 320   # ragged: not a multiple of the band
+    _, full, _ = ds.render(cfg, w, h)
+    for parts, band in ((2, 8), (3, 16), (8, 8)):
+        frame = np.zeros_like(full)
+        for part in range(parts):
+            _, tile, st = ds.render(cfg, w, h, tile=(part, parts, band))
+            rows = [y for y in range(h) if (y // band) % parts == part]
+            assert st["rows_rendered"] == len(rows) == tile.shape[0]
+            frame[rows] = tile
+        assert_exact(frame, full)
