@@ -180,7 +180,12 @@ def cpu_baseline(desc, cfg, W, H, budget_s):
     """The oracle (test infrastructure, a port of the reference algorithm) timed on this box's cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    cores = os.cpu_count() or 1
+    # the GPU box gives a one-GPU job a share of 16 host cores (the machine has more); use that share
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("RAYCA_CPU_THREADS", min(avail, 16)))
     orc = ol.OracleScene(desc, cfg, build=ol.BUILD_BINNED, xform=ol.XFORM_PER_TEST, threads=cores)
     # probe: every `parts`-th row, starting sparse
     parts = max(H // 8, 1)

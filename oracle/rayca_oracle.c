@@ -1876,12 +1876,18 @@ static void* render_worker(void* arg) {
   memset(&cx, 0, sizeof cx);
   cx.scene = job->s; cx.cfg = job->cfg;
   uint64_t primary = 0;
+  /* work item = 64 consecutive pixels of one row (finer than rows so that a sparse row sample
+   * still keeps every core busy) */
+  const uint32_t chunks_per_row = (job->width + 63u) / 64u;
+  const uint32_t items = job->row_count * chunks_per_row;
   for (;;) {
-    uint32_t r = __sync_fetch_and_add(&job->next_row, 1u);
-    if (r >= job->row_count) break;
+    uint32_t it = __sync_fetch_and_add(&job->next_row, 1u);
+    if (it >= items) break;
+    uint32_t r = it / chunks_per_row, x0 = (it % chunks_per_row) * 64u;
+    uint32_t x1 = x0 + 64u < job->width ? x0 + 64u : job->width;
     uint32_t y = job->rows[r];
-    for (uint32_t x = 0; x < job->width; ++x) render_pixel(&cx, job, x, y, r);
-    primary += (uint64_t)job->width * job->cfg->samples_per_pixel;
+    for (uint32_t x = x0; x < x1; ++x) render_pixel(&cx, job, x, y, r);
+    primary += (uint64_t)(x1 - x0) * job->cfg->samples_per_pixel;
   }
   pthread_mutex_lock(&job->mu);
   job->stats.rays_primary += primary;
@@ -1908,7 +1914,10 @@ static int32_t render_rows_list(OracleScene* s, const RaycaConfig* cfg, uint32_t
   job.rgba8 = rgba8; job.rgba32f = rgba32f;
   pthread_mutex_init(&job.mu, NULL);
   uint32_t nt = s->opts.threads;
-  if (nt > row_count) nt = row_count ? row_count : 1;
+  {
+    uint64_t items = (uint64_t)row_count * ((width + 63u) / 64u);
+    if (nt > items) nt = items ? (uint32_t)items : 1;
+  }
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nt);
   double t0 = now_s();
   for (uint32_t i = 0; i < nt; ++i) pthread_create(&th[i], NULL, render_worker, &job);
