@@ -108,15 +108,20 @@ struct LaneCounters {
   uint32_t boxes = 0, tris = 0;
 };
 
+constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index that never exists
+
 // Closest hit along `r` (Tlas::intersects).  stack = this lane's LDS column, entries `stride` apart.
 //   ORDERED    front-to-back descent, subtrees whose entry distance exceeds the current best are
-//              skipped.  The winner is the (t, primitive index) lexicographic minimum, which is what
+//              skipped.  The winner is the (t, reference order) lexicographic minimum, which is what
 //              the reference's strict-< DFS returns (blas.rs:151,161,169).  The skip test carries a
 //              slack (relative 2^-10 plus sc.cull_abs) because a triangle's t and its box's slab
 //              entry are computed by different expressions and may disagree in the last bits.
 //   !ORDERED   visits exactly the boxes the reference visits (no culling).
 //   t_stop     any-hit early out: stop as soon as a hit with t < t_stop is found (shadow rays,
 //              "occluded iff closest depth < light distance", nee.rs:152-156).  FLT_MAX = never.
+// Structure: "while-while" -- all lanes of the wave first descend inner nodes until each holds a leaf
+// (or has finished), then the leaf lanes run the triangle tests together, so the expensive leaf code
+// is not serialised against node steps of other lanes.
 template <bool ORDERED, bool STATS>
 __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, uint32_t* stack, uint32_t stride, DHit& hit, LaneCounters& cnt) {
   hit.t = INFINITY;
@@ -124,14 +129,38 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
   hit.u = hit.v = 0.0f;
   float tmin;
   if (STATS) cnt.boxes++;
-  if (!slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], r, tmin)) return false;
-  uint32_t sp = 0;
   uint32_t cur = sc.root_ref;
+  if (!slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], r, tmin)) cur = kTerminated;
+  uint32_t sp = 0;
   const bool any_hit = ORDERED && t_stop < FLT_MAX;
   float limit = INFINITY;  // cull bound (ORDERED only)
   if (any_hit) limit = t_stop + fabsf(t_stop) * 9.765625e-4f + sc.cull_abs;
-  for (;;) {
-    if (cur & kLeafFlag) {
+  while (cur != kTerminated) {
+    while (!(cur & kLeafFlag) && cur != kTerminated) {
+      const float4* np = sc.nodes + 4ull * cur;
+      const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+      float tl, tr;
+      bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
+      bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+      if (STATS) cnt.boxes += 2;
+      const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+      if (ORDERED) {
+        hl = hl && tl <= limit;
+        hr = hr && tr <= limit;
+      }
+      if (hl && hr) {
+        const bool left_first = !ORDERED || tl <= tr;
+        stack[(sp++) * stride] = left_first ? rref : lref;
+        cur = left_first ? lref : rref;
+      } else if (hl) {
+        cur = lref;
+      } else if (hr) {
+        cur = rref;
+      } else {
+        cur = sp ? stack[(--sp) * stride] : kTerminated;
+      }
+    }
+    if (cur != kTerminated) {  // a leaf
       const uint32_t first = cur & kLeafFirstMask;
       const uint32_t count = ((cur >> 25) & 63u) + 1u;
       for (uint32_t i = first; i < first + count; ++i) {
@@ -152,33 +181,8 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
           }
         }
       }
-      if (any_hit && hit.t < t_stop) return true;
-      if (sp == 0) break;
-      cur = stack[(--sp) * stride];
-      continue;
-    }
-    const float4* np = sc.nodes + 4ull * cur;
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-    float tl, tr;
-    bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
-    bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
-    if (STATS) cnt.boxes += 2;
-    const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-    if (ORDERED) {
-      hl = hl && tl <= limit;
-      hr = hr && tr <= limit;
-    }
-    if (hl && hr) {
-      const bool left_first = !ORDERED || tl <= tr;
-      stack[(sp++) * stride] = left_first ? rref : lref;
-      cur = left_first ? lref : rref;
-    } else if (hl) {
-      cur = lref;
-    } else if (hr) {
-      cur = rref;
-    } else {
-      if (sp == 0) break;
-      cur = stack[(--sp) * stride];
+      if (any_hit && hit.t < t_stop) break;
+      cur = sp ? stack[(--sp) * stride] : kTerminated;
     }
   }
   return hit.prim != RAYCA_NONE;
@@ -213,18 +217,6 @@ __device__ Color sample_texture(const DevScene& sc, uint32_t tex, F2 uv) {
   return Color{(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, 255.0f / 255.0f};
 }
 
-struct Surface {
-  const PrimExt* e;
-  DevMaterial m;
-  F4 point, view;  // hit point, -ray.dir
-  float bu, bv;    // barycentrics (u -> vertex 0, v -> vertex 1, 1-u-v -> vertex 2; bvh/triangle.rs:34-38)
-  F2 uv;
-  Color geom_color;
-  Color color;     // get_color: geometry colour x material colour
-  F4 normal;
-  F4 ray_dir;
-};
-
 __device__ __forceinline__ bool tex_valid(const DevScene& sc, uint32_t t) { return t != RAYCA_NONE && t < sc.texture_count; }
 
 __device__ __forceinline__ Color pbr_color(const DevScene& sc, const DevMaterial& m, F2 uv) {  // pbr.rs:94-102
@@ -258,53 +250,60 @@ __device__ __forceinline__ F4 interp3(const float (*a)[3], float bu, float bv) {
   return (load_vec3(a[2]) * w2 + load_vec3(a[0]) * bu) + load_vec3(a[1]) * bv;
 }
 
-// colour-only part (all Flat needs): primitive.rs:142-148
-__device__ __forceinline__ void surface_color(const DevScene& sc, Surface& s) {
-  const PrimExt& e = *s.e;
-  const float w2 = 1.0f - s.bu - s.bv;
-  s.geom_color = (load_color(e.color[2]) * w2 + load_color(e.color[0]) * s.bu) + load_color(e.color[1]) * s.bv;
-  s.uv = F2{(e.uv[2][0] * w2 + e.uv[0][0] * s.bu) + e.uv[1][0] * s.bv, (e.uv[2][1] * w2 + e.uv[0][1] * s.bu) + e.uv[1][1] * s.bv};
-  s.m = (e.material != RAYCA_NONE && e.material < sc.material_count) ? sc.materials[e.material] : default_material();
-  Color mc;
-  if (s.m.kind == RAYCA_MATERIAL_PBR) mc = pbr_color(sc, s.m, s.uv);
-  else if (s.m.kind == RAYCA_MATERIAL_PHONG) mc = load_color(s.m.ambient) + load_color(s.m.emission);
-  else mc = load_color(s.m.diffuse);
-  s.color = s.geom_color * mc;
-}
-// normal: primitive.rs:172-182 -> material/mod.rs:125-139 -> pbr.rs:104-123
-__device__ __forceinline__ void surface_normal(const DevScene& sc, Surface& s) {
-  const PrimExt& e = *s.e;
-  const F4 normal = normalized(interp3(e.normal, s.bu, s.bv));
-  if (s.m.kind == RAYCA_MATERIAL_PBR && tex_valid(sc, s.m.normal_texture)) {
-    const F4 tangent = normalized(interp3(e.tangent, s.bu, s.bv));
-    const F4 bitangent = normalized(interp3(e.bitangent, s.bu, s.bv));
-    F4 sn = premultiplied(sample_texture(sc, s.m.normal_texture, s.uv));
+// HitInfo (rayca-soft/src/hit.rs) reduced to the values the rest of the path vertex needs; everything
+// here is a pure function of the hit, so evaluating it once instead of lazily gives the same bits.
+struct ShadeCtx {
+  F4 point, normal, view, next_origin;  // hit point, shading normal, -ray.dir, point + normal*BIAS
+  Color kd, ks;                         // get_diffuse(), get_specular()
+  float roughness, shininess;
+  uint32_t kind;                        // RAYCA_MATERIAL_*
+};
+
+// get_color (primitive.rs:142-148) always; the rest only when `full` (Pathtracer).
+// barycentrics: u -> vertex 0, v -> vertex 1, 1-u-v -> vertex 2 (bvh/triangle.rs:34-38)
+__device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, const DHit& hit, bool full, Color& color, bool& emissive,
+                                          ShadeCtx& cx) {
+  const PrimExt& e = sc.ext[hit.prim];
+  const float bu = hit.u, bv = hit.v;
+  const float w2 = 1.0f - bu - bv;
+  const Color geom_color = (load_color(e.color[2]) * w2 + load_color(e.color[0]) * bu) + load_color(e.color[1]) * bv;
+  const F2 uv{(e.uv[2][0] * w2 + e.uv[0][0] * bu) + e.uv[1][0] * bv, (e.uv[2][1] * w2 + e.uv[0][1] * bu) + e.uv[1][1] * bv};
+  const DevMaterial m = (e.material != RAYCA_NONE && e.material < sc.material_count) ? sc.materials[e.material] : default_material();
+  Color mc;  // Material::get_color  material/mod.rs:107-113
+  if (m.kind == RAYCA_MATERIAL_PBR) mc = pbr_color(sc, m, uv);
+  else if (m.kind == RAYCA_MATERIAL_PHONG) mc = load_color(m.ambient) + load_color(m.emission);
+  else mc = load_color(m.diffuse);
+  color = geom_color * mc;
+  emissive = m.emissive != 0u;
+  if (!full) return;
+  // normal: primitive.rs:172-182 -> material/mod.rs:125-139 -> pbr.rs:104-123
+  F4 normal = normalized(interp3(e.normal, bu, bv));
+  if (m.kind == RAYCA_MATERIAL_PBR && tex_valid(sc, m.normal_texture)) {
+    const F4 tangent = normalized(interp3(e.tangent, bu, bv));
+    const F4 bitangent = normalized(interp3(e.bitangent, bu, bv));
+    F4 sn = premultiplied(sample_texture(sc, m.normal_texture, uv));
     sn = sn * 2.0f - f4(1.0f, 1.0f, 1.0f, 1.0f);
-    s.normal = normalized(mat3_apply(mat3_tbn(tangent, bitangent, normal), sn));
+    normal = normalized(mat3_apply(mat3_tbn(tangent, bitangent, normal), sn));
+  }
+  cx.normal = normal;
+  cx.point = ray.o + ray.d * hit.t;  // Hit.point  triangle.rs:122
+  cx.view = -ray.d;                  // ray.rs:149-151
+  cx.next_origin = cx.point + normal * kRayBias;  // hit.rs:164-171
+  cx.kind = m.kind;
+  cx.shininess = m.shininess;
+  // get_diffuse  primitive.rs:150-155 ; get_specular / get_roughness  material/mod.rs:141-151,173-185
+  if (m.kind == RAYCA_MATERIAL_PBR) {
+    float me, ro;
+    pbr_metallic_roughness(sc, m, uv, me, ro);
+    const Color base = pbr_color(sc, m, uv);
+    cx.kd = geom_color * base;
+    cx.ks = me * base;
+    cx.roughness = ro;
   } else {
-    s.normal = normal;
+    cx.kd = geom_color * load_color(m.diffuse);
+    cx.ks = load_color(m.specular);
+    cx.roughness = m.kind == RAYCA_MATERIAL_PHONG ? clampf(sqrtf(2.0f / (m.shininess + 2.0f)), 0.0f, 1.0f) : m.roughness_factor;
   }
-}
-__device__ __forceinline__ Color surf_diffuse(const DevScene& sc, const Surface& s) {  // primitive.rs:150-155
-  const Color md = s.m.kind == RAYCA_MATERIAL_PBR ? pbr_color(sc, s.m, s.uv) : load_color(s.m.diffuse);
-  return s.geom_color * md;
-}
-__device__ __forceinline__ Color surf_specular(const DevScene& sc, const Surface& s) {  // material/mod.rs:141-151
-  if (s.m.kind == RAYCA_MATERIAL_PBR) {
-    float me, ro;
-    pbr_metallic_roughness(sc, s.m, s.uv, me, ro);
-    return me * pbr_color(sc, s.m, s.uv);
-  }
-  return load_color(s.m.specular);
-}
-__device__ __forceinline__ float surf_roughness(const DevScene& sc, const Surface& s) {  // material/mod.rs:173-185
-  if (s.m.kind == RAYCA_MATERIAL_PHONG) return clampf(sqrtf(2.0f / (s.m.shininess + 2.0f)), 0.0f, 1.0f);
-  if (s.m.kind == RAYCA_MATERIAL_PBR) {
-    float me, ro;
-    pbr_metallic_roughness(sc, s.m, s.uv, me, ro);
-    return ro;
-  }
-  return s.m.roughness_factor;
 }
 
 // ---- BRDFs: brdf/ggx.rs:58-129, brdf/lambertian.rs:7-16 -----------------------------------------
@@ -326,34 +325,29 @@ __device__ __forceinline__ Color ggx_f(Color ks, F4 omega_i, F4 h) {
   const float oh = fabsf(dot(omega_i, h));
   return ks + (white() - ks) * powf(1.0f - oh, 5.0f);
 }
-__device__ Color ggx_brdf(const DevScene& sc, const Surface& s, F4 omega_i) {
-  const Color kd = surf_diffuse(sc, s);
-  Color bsdf = black();
+__device__ __noinline__ Color surf_brdf(const ShadeCtx& s, F4 omega_i) {  // HitInfo::get_brdf  hit.rs:220-227
+  if (s.kind == RAYCA_MATERIAL_PHONG) {  // lambertian::get_brdf
+    const Color lambertian = s.kd * kFrac1Pi;
+    const float sh = s.shininess;
+    const F4 refl = normalized(reflect(-s.view, s.normal));  // hit.rs:93-101 (ray.dir == -view exactly)
+    const Color specular = (((s.ks * (sh + 2.0f)) * powf(dot(refl, omega_i), sh)) * kFrac1Pi) / 2.0f;
+    return lambertian + specular;
+  }
+  Color bsdf = black();  // ggx::get_bsdf
   const F4 omega_o = s.view;
   const F4 n = s.normal;
   const float oin = clampf(dot(omega_i, n), 0.0f, 1.0f);
   const float oon = clampf(dot(omega_o, n), 0.0f, 1.0f);
   if (!(oin == 0.0f || oon == 0.0f)) {
-    const Color ks = surf_specular(sc, s);
-    const float a = surf_roughness(sc, s);
+    const float a = s.roughness;
     const F4 h = normalized(omega_i + omega_o);
-    const Color f = ggx_f(ks, omega_i, h);
+    const Color f = ggx_f(s.ks, omega_i, h);
     const float g = ggx_g1(a, omega_i, n) * ggx_g1(a, omega_o, n);
     const float d = ggx_d(a, h, n);
     const float denominator = 4.0f * oin * oon;
     bsdf = ((f * g) * d) / denominator;
   }
-  return kd * kFrac1Pi + bsdf;
-}
-__device__ Color lambert_brdf(const DevScene& sc, const Surface& s, F4 omega_i) {
-  const Color lambertian = surf_diffuse(sc, s) * kFrac1Pi;
-  const float sh = s.m.shininess;
-  const F4 refl = normalized(reflect(s.ray_dir, s.normal));  // hit.rs:93-101
-  const Color specular = (((surf_specular(sc, s) * (sh + 2.0f)) * powf(dot(refl, omega_i), sh)) * kFrac1Pi) / 2.0f;
-  return lambertian + specular;
-}
-__device__ __forceinline__ Color surf_brdf(const DevScene& sc, const Surface& s, F4 omega_i) {  // hit.rs:220-227
-  return s.m.kind == RAYCA_MATERIAL_PHONG ? lambert_brdf(sc, s, omega_i) : ggx_brdf(sc, s, omega_i);
+  return s.kd * kFrac1Pi + bsdf;
 }
 
 // ---- work distribution ---------------------------------------------------------------------------
@@ -439,73 +433,68 @@ __device__ __forceinline__ void push_ray(bool has, const QueuedRay& qr, QueuedRa
 
 constexpr int kModeFlat = 0, kModePath = 1;
 
-// NextEventEstimationSampler::get_direct_lighting  sampler/nee.rs:127-216
-template <bool ORDERED, bool STATS>
-__device__ Color nee_direct(const DevScene& sc, const FrameParams& fp, const Surface& s, F4 next_origin, uint32_t key, uint32_t& dim,
-                            uint32_t* stack, uint32_t stride, LaneCounters& cnt, uint32_t& shadow_rays) {
-  Color ret = black();
-  for (uint32_t li = 0; li < sc.light_count; ++li) {
-    const DevLight L = sc.lights[li];
-    for (uint32_t k = 0; k < fp.light_samples; ++k) {
-      Color x = black();
-      if (L.kind == RAYCA_LIGHT_POINT) {  // get_point_light_sample  nee.rs:127-166
-        const F4 x1 = f4(L.position[0], L.position[1], L.position[2], L.position[3]);
-        const F4 x_to_x1 = as_vec(x1 - s.point);
-        const float dist = length(x_to_x1);
-        const F4 omega = normalized(x_to_x1);
-        const DRay sr = make_ray(next_origin, omega);
-        DHit sh;
-        shadow_rays++;
-        // occluded iff the closest hit is nearer than the light  <=>  any hit with t < dist
-        const bool occluded = trace<ORDERED, STATS>(sc, sr, dist, stack, stride, sh, cnt) && sh.t < dist;
-        if (!occluded) {
-          // PointLight::get_intensity / get_fallof  light/point.rs:37-49
-          const F4 dvec = to_vec(s.point) - as_vec(x1 - f4(0, 0, 0, 1.0f));
-          const float r2 = norm2(dvec);
-          const float rr = sqrtf(r2);
-          const float fallof = hsum(f4(L.attenuation[0], L.attenuation[1], L.attenuation[2], 0.0f) * f4(1.0f, rr, r2, 0.0f));
-          const Color le = (L.intensity * load_color(L.color)) / fallof;
-          const Color brdf = surf_brdf(sc, s, omega);
-          const float r_squared = norm2(x_to_x1);
-          const float d_omega = 1.0f / r_squared;
-          const float n_dot_omega = clampf(dot(s.normal, omega), 0.0f, 1.0f);
-          x = ((le * brdf) * n_dot_omega) * d_omega;
-        }
-      } else if (L.kind == RAYCA_LIGHT_QUAD) {  // get_quad_light_sample  nee.rs:72-125
-        const F4 ab = f4(L.ab[0], L.ab[1], L.ab[2], 0.0f), ac = f4(L.ac[0], L.ac[1], L.ac[2], 0.0f);
-        const float sc_f = (float)fp.strate_count;
-        const float u1 = rng_f32(key, dim++) / sc_f;
-        const float u2 = rng_f32(key, dim++) / sc_f;
-        const F4 a = f4(L.position[0], L.position[1], L.position[2], L.position[3]);
-        F4 x1 = (a + u1 * ab) + u2 * ac;  // quad.rs:112-135
-        if (fp.light_stratify) {
-          const float i1 = (float)(k % fp.strate_count), i2 = (float)(k / fp.strate_count);
-          x1 = x1 + ((ab / sc_f) * i1 + (ac / sc_f) * i2);
-        }
-        const F4 x_to_x1 = as_vec(x1 - s.point);
-        const F4 omega = normalized(x_to_x1);
-        const DRay sr = make_ray(next_origin, omega);
-        DHit sh;
-        shadow_rays++;
-        if (trace<ORDERED, STATS>(sc, sr, FLT_MAX, stack, stride, sh, cnt)) {
-          const PrimExt& he = sc.ext[sh.prim];
-          const bool emissive = he.material != RAYCA_NONE && he.material < sc.material_count && sc.materials[he.material].emissive;
-          if (emissive) {
-            const Color le = L.intensity * load_color(L.color);
-            const Color brdf = surf_brdf(sc, s, omega);
-            const float r_squared = norm2(x_to_x1);
-            const float d_omega = dot(f4(L.normal[0], L.normal[1], L.normal[2], 0.0f), omega) / r_squared;
-            const float n_dot_omega = clampf(dot(s.normal, omega), 0.0f, 1.0f);
-            x = (((le * L.area) * brdf) * n_dot_omega) * d_omega;
-          }
-        }
-      }
-      ret = ret + x;
+// One NEE sample (sampler/nee.rs:72-166), split around its shadow ray: everything that does not depend
+// on the shadow ray's outcome is evaluated first (pure functions, same values), so that only the
+// candidate contribution `x` has to survive the traversal.
+struct NeeSample {
+  Color x;       // contribution if the light turns out to be visible
+  float t_stop;  // point light: its distance (any-hit bound); quad light: FLT_MAX (closest hit wanted)
+  uint32_t quad; // 1: "lit iff the closest hit is emissive" (nee.rs:103-104)
+};
+__device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const FrameParams& fp, const ShadeCtx& s, uint32_t li, uint32_t k,
+                                                 uint32_t key, uint32_t& dim, DRay& shadow_ray) {
+  const DevLight L = sc.lights[li];
+  NeeSample ns;
+  const F4 x_point = s.point;
+  if (L.kind == RAYCA_LIGHT_POINT) {  // get_point_light_sample  nee.rs:127-166
+    const F4 x1 = f4(L.position[0], L.position[1], L.position[2], L.position[3]);
+    const F4 x_to_x1 = as_vec(x1 - x_point);
+    const float dist = length(x_to_x1);
+    const F4 omega = normalized(x_to_x1);
+    shadow_ray = make_ray(s.next_origin, omega);
+    // PointLight::get_intensity / get_fallof  light/point.rs:37-49
+    const F4 dvec = to_vec(x_point) - to_vec(x1);
+    const float r2 = norm2(dvec);
+    const float rr = sqrtf(r2);
+    const float fallof = hsum(f4(L.attenuation[0], L.attenuation[1], L.attenuation[2], 0.0f) * f4(1.0f, rr, r2, 0.0f));
+    const Color le = (L.intensity * load_color(L.color)) / fallof;
+    const Color brdf = surf_brdf(s, omega);
+    const float r_squared = norm2(x_to_x1);
+    const float d_omega = 1.0f / r_squared;
+    const float n_dot_omega = clampf(dot(s.normal, omega), 0.0f, 1.0f);
+    ns.x = ((le * brdf) * n_dot_omega) * d_omega;
+    ns.t_stop = dist;
+    ns.quad = 0u;
+  } else {  // get_quad_light_sample  nee.rs:72-125 ; QuadLight::get_random_point  light/quad.rs:112-135
+    const F4 ab = f4(L.ab[0], L.ab[1], L.ab[2], 0.0f), ac = f4(L.ac[0], L.ac[1], L.ac[2], 0.0f);
+    const float sc_f = (float)fp.strate_count;
+    const float u1 = rng_f32(key, dim++) / sc_f;
+    const float u2 = rng_f32(key, dim++) / sc_f;
+    const F4 a = f4(L.position[0], L.position[1], L.position[2], L.position[3]);
+    F4 x1 = (a + u1 * ab) + u2 * ac;
+    if (fp.light_stratify) {
+      const float i1 = (float)(k % fp.strate_count), i2 = (float)(k / fp.strate_count);
+      x1 = x1 + ((ab / sc_f) * i1 + (ac / sc_f) * i2);
     }
+    const F4 x_to_x1 = as_vec(x1 - x_point);
+    const F4 omega = normalized(x_to_x1);
+    shadow_ray = make_ray(s.next_origin, omega);
+    const Color le = L.intensity * load_color(L.color);
+    const Color brdf = surf_brdf(s, omega);
+    const float r_squared = norm2(x_to_x1);
+    const float d_omega = dot(f4(L.normal[0], L.normal[1], L.normal[2], 0.0f), omega) / r_squared;
+    const float n_dot_omega = clampf(dot(s.normal, omega), 0.0f, 1.0f);
+    ns.x = (((le * L.area) * brdf) * n_dot_omega) * d_omega;
+    ns.t_stop = FLT_MAX;
+    ns.quad = 1u;
   }
-  return ret;
+  return ns;
 }
 
+// One generation of rays.  Per lane a small state machine around ONE traversal call site:
+//   primary ray -> shade -> [NEE shadow ray]* -> bounce sample -> done
+// so the traversal loop is instantiated once per kernel and the registers that must survive it are
+// the ray, the hit, the compact ShadeCtx and a few colours.
 template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
@@ -520,105 +509,137 @@ __global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams 
   const uint32_t total = GEN0 ? fp.tile_count : (*in_count + 63u) / 64u;
   LaneCounters cnt;
   uint32_t n_shaded = 0, n_shadow = 0, n_bounce = 0;
+  const bool collect_emissive = GEN0 ? true : (fp.direct_sampler == RAYCA_SAMPLER_NONE);
+  const uint32_t nee_lights = (MODE == kModePath && fp.direct_sampler == RAYCA_SAMPLER_NEE) ? sc.light_count : 0u;
 
   for (;;) {
     const uint32_t batch = next_batch(heads, total, home, exhausted);
     if (batch == RAYCA_NONE) break;
-    bool active;
+    bool live;
     uint32_t p = 0, key = 0;
     DRay ray;
     if (GEN0) {
       const uint32_t ty = batch / fp.tiles_x, tx = batch - ty * fp.tiles_x;
       const uint32_t x = tx * 8u + (lane & 7u), r = ty * 8u + (lane >> 3);
-      active = x < fp.width && r < fp.rows;
+      live = x < fp.width && r < fp.rows;
       const uint32_t y = ((r / fp.band) * fp.parts + fp.part) * fp.band + (r % fp.band);
       p = r * fp.width + x;
-      if (active) {
+      if (live) {
         ray = camera_ray(fp, x, y);
         key = rng_root(fp.seed, y * fp.width + x, fp.sample);
       }
     } else {
       const uint32_t i = batch * 64u + lane;
-      active = i < *in_count;
-      if (active) {
+      live = i < *in_count;
+      if (live) {
         const QueuedRay q = in_rays[i];
         ray = make_ray(point3(q.ox, q.oy, q.oz), vec3(q.dx, q.dy, q.dz));
         p = q.pixel;
         key = q.key;
       }
     }
+    const size_t slot = (size_t)depth * pb.npix + p;
     bool want_bounce = false;
     QueuedRay next{};
-    if (active) {
+    bool in_shadow = false;
+    float t_stop = FLT_MAX;
+    ShadeCtx cx;
+    NeeSample ns;
+    ns.x = black();
+    ns.t_stop = FLT_MAX;
+    ns.quad = 0u;
+    Color direct = black();
+    uint32_t li = 0, k = 0, dim = 0;
+
+    while (live) {
       DHit hit;
-      const bool found = trace<ORDERED, STATS>(sc, ray, FLT_MAX, stack, stride, hit, cnt);
-      const size_t slot = (size_t)depth * pb.npix + p;
-      if (!found) {
-        if (FUSED) finalize_pixel(fp, black() + black(), p, rgba8, rgba32f);  // unwrap_or(BLACK), color += it
-        else pb.state[slot] = kVertexNone;
-      } else {
-        n_shaded++;
-        Surface s;
-        s.e = &sc.ext[hit.prim];
-        s.bu = hit.u;
-        s.bv = hit.v;
-        s.point = ray.o + ray.d * hit.t;
-        s.view = -ray.d;
-        s.ray_dir = ray.d;
-        surface_color(sc, s);
-        if (MODE == kModeFlat) {  // Flat::trace  integrator/flat.rs:16-28
-          if (FUSED) finalize_pixel(fp, black() + s.color, p, rgba8, rgba32f);
-          else {
-            pb.direct[slot] = as_f4(s.color);
-            pb.state[slot] = kVertexEmissive;
-          }
-        } else {  // Pathtracer::trace_impl  integrator/pathtracer.rs:68-106
-          const bool collect_emissive = GEN0 ? true : (fp.direct_sampler == RAYCA_SAMPLER_NONE);
-          if (collect_emissive && s.m.emissive) {
-            pb.direct[slot] = as_f4(s.color);
-            pb.state[slot] = kVertexEmissive;
-          } else {
-            surface_normal(sc, s);
-            const F4 next_origin = s.point + s.normal * kRayBias;  // hit.rs:164-171
-            uint32_t dim = 0;
-            Color direct = black();
-            if (fp.direct_sampler == RAYCA_SAMPLER_NEE) direct = nee_direct<ORDERED, STATS>(sc, fp, s, next_origin, key, dim, stack, stride, cnt, n_shadow);
-            const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
-            pb.direct[slot] = as_f4(direct);
-            if (depth < limit) {
-              // CosineSampler::get_random_dir  sampler/cosine.rs:65-88
-              const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
-              float theta, omega_a = 2.0f * kPi * e2;
-              if (fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE) theta = acosf(e1);  // hemisphere.rs:17-40
-              else theta = acosf(sqrtf(e1));
-              const F4 sdir = vec3(cosf(omega_a) * sinf(theta), sinf(omega_a) * sinf(theta), cosf(theta));
-              const F4 w = s.normal;
-              const F4 a = close(w, vec3(0, 1, 0)) ? vec3(1, 0, 0) : vec3(0, 1, 0);
-              const F4 u = normalized(cross(a, w));
-              F4 v = cross(w, u);
-              if (fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE) v = normalized(v);
-              const F4 omega_i = (sdir.x * u + sdir.y * v) + sdir.z * w;
-              const Color brdf = surf_brdf(sc, s, omega_i);
-              // the factor SoftSampler::get_radiance applies to the incoming radiance, evaluated in its
-              // order up to the point where the child's result enters: cosine.rs:90-99 `PI * brdf`,
-              // hemisphere.rs:42-52 `2.0 * PI * brdf * cosine_law`
-              Color factor;
-              if (fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE) factor = ((2.0f * kPi) * brdf) * clampf(dot(s.normal, omega_i), 0.0f, 1.0f);
-              else factor = kPi * brdf;
-              pb.brdf[slot] = as_f4(factor);
-              pb.state[slot] = kVertexLit;
-              if (depth + 1u < fp.max_depth) {
-                want_bounce = true;
-                next.ox = next_origin.x; next.oy = next_origin.y; next.oz = next_origin.z;
-                next.dx = omega_i.x; next.dy = omega_i.y; next.dz = omega_i.z;
-                next.pixel = p;
-                next.key = rng_child(key, 0u);
-                n_bounce++;
-              }
-            } else {
-              pb.state[slot] = kVertexLitNoIndirect;
+      const bool found = trace<ORDERED, STATS>(sc, ray, t_stop, stack, stride, hit, cnt);
+      if (!in_shadow) {
+        if (!found) {
+          if (FUSED) finalize_pixel(fp, black() + black(), p, rgba8, rgba32f);  // unwrap_or(BLACK), color += it
+          else pb.state[slot] = kVertexNone;
+          live = false;
+        } else {
+          n_shaded++;
+          Color color;
+          bool emissive;
+          shade_hit(sc, ray, hit, MODE == kModePath, color, emissive, cx);
+          if (MODE == kModeFlat) {  // Flat::trace  integrator/flat.rs:16-28
+            if (FUSED) finalize_pixel(fp, black() + color, p, rgba8, rgba32f);
+            else {
+              pb.direct[slot] = as_f4(color);
+              pb.state[slot] = kVertexEmissive;
             }
+            live = false;
+          } else if (collect_emissive && emissive) {  // pathtracer.rs:83-87
+            pb.direct[slot] = as_f4(color);
+            pb.state[slot] = kVertexEmissive;
+            live = false;
+          } else {
+            in_shadow = true;  // enter the NEE loop (possibly empty)
           }
+        }
+      } else {
+        // outcome of the pending NEE sample
+        bool lit;
+        if (ns.quad) {
+          lit = false;
+          if (found) {
+            const uint32_t hm = sc.ext[hit.prim].material;
+            lit = hm != RAYCA_NONE && hm < sc.material_count && sc.materials[hm].emissive != 0u;
+          }
+        } else {
+          lit = !(found && hit.t < ns.t_stop);  // nee.rs:152-156
+        }
+        direct = direct + (lit ? ns.x : black());
+        if (++k == fp.light_samples) {
+          k = 0;
+          ++li;
+        }
+      }
+      if (live && in_shadow) {
+        if (li < nee_lights) {
+          ns = nee_prepare(sc, fp, cx, li, k, key, dim, ray);
+          t_stop = ns.t_stop;
+          n_shadow++;
+        } else {
+          // all direct samples done: Pathtracer::trace_impl tail  pathtracer.rs:89-105
+          const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
+          pb.direct[slot] = as_f4(direct);
+          if (depth < limit) {
+            // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40
+            const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
+            const bool hemi = fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE;
+            const float theta = hemi ? acosf(e1) : acosf(sqrtf(e1));
+            const float omega_a = 2.0f * kPi * e2;
+            const F4 sdir = vec3(cosf(omega_a) * sinf(theta), sinf(omega_a) * sinf(theta), cosf(theta));
+            const F4 w = cx.normal;
+            const F4 a = close(w, vec3(0, 1, 0)) ? vec3(1, 0, 0) : vec3(0, 1, 0);
+            const F4 u = normalized(cross(a, w));
+            F4 v = cross(w, u);
+            if (hemi) v = normalized(v);
+            const F4 omega_i = (sdir.x * u + sdir.y * v) + sdir.z * w;
+            const Color brdf = surf_brdf(cx, omega_i);
+            // the factor SoftSampler::get_radiance applies to the incoming radiance, evaluated in its
+            // order up to the point where the child's result enters: cosine.rs:90-99 `PI * brdf`,
+            // hemisphere.rs:42-52 `2.0 * PI * brdf * cosine_law`
+            Color factor;
+            if (hemi) factor = ((2.0f * kPi) * brdf) * clampf(dot(cx.normal, omega_i), 0.0f, 1.0f);
+            else factor = kPi * brdf;
+            pb.brdf[slot] = as_f4(factor);
+            pb.state[slot] = kVertexLit;
+            if (depth + 1u < fp.max_depth) {
+              want_bounce = true;
+              next.ox = cx.next_origin.x; next.oy = cx.next_origin.y; next.oz = cx.next_origin.z;
+              next.dx = omega_i.x; next.dy = omega_i.y; next.dz = omega_i.z;
+              next.pixel = p;
+              next.key = rng_child(key, 0u);
+              n_bounce++;
+            }
+          } else {
+            pb.state[slot] = kVertexLitNoIndirect;
+          }
+          live = false;
         }
       }
     }
@@ -638,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams 
       atomicAdd(&counters->shaded, sh);
     }
   }
-  {
+  if (MODE == kModePath) {
     unsigned long long s2 = n_shadow, b2 = n_bounce;
     for (int off = 32; off > 0; off >>= 1) {
       s2 += __shfl_down(s2, off);
