@@ -301,6 +301,11 @@ typedef struct RaycaStats {
   uint64_t boxes_tested;     /* only with collect_stats: AABB slab tests (32 B each)            */
   uint64_t triangles_tested; /* only with collect_stats: ray/triangle tests (36 B each)         */
   uint64_t hits_shaded;      /* only with collect_stats */
+  /* only with collect_stats: SIMD-slot accounting of the traversal.  For every 64-ray batch the
+   * kernel adds 64 x (the largest per-lane box-test / triangle-test count in the wave): what a
+   * lock-step wave pays.  boxes_tested / wave_box_slots is the lane utilisation of the node loop. */
+  uint64_t wave_box_slots;
+  uint64_t wave_triangle_slots;
   float kernel_ms;           /* HIP-event time over all kernels of the frame, on the launch stream */
   float trace_kernel_ms;     /* the traversal kernels alone (the roofline kernel)                */
   uint32_t kernel_launches;

@@ -199,6 +199,8 @@ class RaycaStats(C.Structure):
         ("boxes_tested", C.c_uint64),
         ("triangles_tested", C.c_uint64),
         ("hits_shaded", C.c_uint64),
+        ("wave_box_slots", C.c_uint64),
+        ("wave_triangle_slots", C.c_uint64),
         ("kernel_ms", C.c_float),
         ("trace_kernel_ms", C.c_float),
         ("kernel_launches", C.c_uint32),

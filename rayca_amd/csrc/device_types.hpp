@@ -64,7 +64,7 @@ struct FrameParams {
 };
 
 struct TraceCounters {
-  unsigned long long boxes, tris, shaded, shadow, bounce;
+  unsigned long long boxes, tris, shaded, shadow, bounce, box_slots, tri_slots;
 };
 
 // ray queue entry between two generations (32 B)

@@ -22,6 +22,9 @@ namespace rayca {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef RAYCA_MIN_WAVES
+#define RAYCA_MIN_WAVES 1
+#endif
 
 struct DRay {
   F4 o, d, rd;  // origin (w=1), direction (w=0), zero-safe reciprocal
@@ -81,19 +84,24 @@ __device__ __forceinline__ bool tri_test(F4 v0, F4 v1, F4 v2, const DRay& r, flo
   return true;
 }
 
+// World-space triangle i: nine f32, 36-B stride, in leaf order.  (Compile with -DRAYCA_TRI_SOA to
+// read nine SoA planes instead -- kept only for the layout A/B in DESIGN.md section 3.)
+struct __attribute__((packed, aligned(4))) Tri9 {
+  float v[9];
+};
 __device__ __forceinline__ void load_tri(const DevScene& sc, uint32_t i, F4& v0, F4& v1, F4& v2) {
-  if (sc.tri_soa) {
-    const float* p = sc.tris + i;
-    const size_t n = sc.prim_count;
-    v0 = vec3(p[0], p[n], p[2 * n]);
-    v1 = vec3(p[3 * n], p[4 * n], p[5 * n]);
-    v2 = vec3(p[6 * n], p[7 * n], p[8 * n]);
-  } else {
-    const float* p = sc.tris + 9ull * i;
-    v0 = vec3(p[0], p[1], p[2]);
-    v1 = vec3(p[3], p[4], p[5]);
-    v2 = vec3(p[6], p[7], p[8]);
-  }
+#if defined(RAYCA_TRI_SOA)
+  const float* p = sc.tris + i;
+  const size_t n = sc.prim_count;
+  v0 = vec3(p[0], p[n], p[2 * n]);
+  v1 = vec3(p[3 * n], p[4 * n], p[5 * n]);
+  v2 = vec3(p[6 * n], p[7 * n], p[8 * n]);
+#else
+  const Tri9 t = *reinterpret_cast<const Tri9*>(sc.tris + 9ull * i);
+  v0 = vec3(t.v[0], t.v[1], t.v[2]);
+  v1 = vec3(t.v[3], t.v[4], t.v[5]);
+  v2 = vec3(t.v[6], t.v[7], t.v[8]);
+#endif
 }
 
 // exact depth tie: the primitive that comes first in the reference's order wins (strict `<` in a
@@ -359,15 +367,29 @@ __device__ __forceinline__ uint32_t xcc_id() {
 // Next 64-wide batch for this wave, or RAYCA_NONE.  The batch list is cut into 8 contiguous
 // partitions, one per XCD: waves drain their own XCD's partition first (neighbouring image tiles ->
 // the same L2), then steal from the others.  Placement only affects speed, never results.
-__device__ __forceinline__ uint32_t next_batch(uint32_t* heads, uint32_t total, uint32_t home, uint32_t& exhausted) {
-  while (exhausted < 8u) {
-    const uint32_t part = (home + exhausted) & 7u;
+// Tickets: each of the 8 counters lives on its own 256-B line (kHeadStride dwords apart) -- atomics on
+// one line serialise in one L2 channel at ~12 ns each, which for 32k batches would be as long as the
+// whole kernel -- and one ticket covers kBatchesPerTicket consecutive batches.
+constexpr uint32_t kHeadStride = 64;
+constexpr uint32_t kBatchesPerTicket = 2;
+struct WorkCursor {
+  uint32_t exhausted = 0;  // partitions found empty so far
+  uint32_t next = 0, end = 0;  // batches of the current ticket still to do
+};
+__device__ __forceinline__ uint32_t next_batch(uint32_t* heads, uint32_t total, uint32_t home, WorkCursor& wc) {
+  if (wc.next < wc.end) return wc.next++;
+  while (wc.exhausted < 8u) {
+    const uint32_t part = (home + wc.exhausted) & 7u;
     const uint32_t lo = (uint32_t)(((uint64_t)part * total) >> 3), hi = (uint32_t)(((uint64_t)(part + 1u) * total) >> 3);
     uint32_t idx = 0;
-    if (__lane_id() == 0) idx = atomicAdd(&heads[part], 1u);
+    if (__lane_id() == 0) idx = atomicAdd(&heads[part * kHeadStride], kBatchesPerTicket);
     idx = __builtin_amdgcn_readfirstlane(idx);
-    if (idx < hi - lo) return lo + idx;
-    exhausted++;
+    if (idx < hi - lo) {
+      wc.next = lo + idx + 1u;
+      wc.end = min(lo + idx + kBatchesPerTicket, hi);
+      return lo + idx;
+    }
+    wc.exhausted++;
   }
   return RAYCA_NONE;
 }
@@ -496,7 +518,7 @@ __device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const Frame
 // so the traversal loop is instantiated once per kernel and the registers that must survive it are
 // the ray, the hit, the compact ShadeCtx and a few colours.
 template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
+__global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
                                                        PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
                                                        TraceCounters* counters) {
@@ -505,15 +527,16 @@ __global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams 
   const uint32_t stride = kBlock;
   const uint32_t lane = __lane_id();
   const uint32_t home = xcc_id();
-  uint32_t exhausted = 0;
+  WorkCursor wc;
   const uint32_t total = GEN0 ? fp.tile_count : (*in_count + 63u) / 64u;
   LaneCounters cnt;
   uint32_t n_shaded = 0, n_shadow = 0, n_bounce = 0;
+  unsigned long long slot_boxes = 0, slot_tris = 0;
   const bool collect_emissive = GEN0 ? true : (fp.direct_sampler == RAYCA_SAMPLER_NONE);
   const uint32_t nee_lights = (MODE == kModePath && fp.direct_sampler == RAYCA_SAMPLER_NEE) ? sc.light_count : 0u;
 
   for (;;) {
-    const uint32_t batch = next_batch(heads, total, home, exhausted);
+    const uint32_t batch = next_batch(heads, total, home, wc);
     if (batch == RAYCA_NONE) break;
     bool live;
     uint32_t p = 0, key = 0;
@@ -553,7 +576,22 @@ __global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams 
 
     while (live) {
       DHit hit;
+      const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
       const bool found = trace<ORDERED, STATS>(sc, ray, t_stop, stack, stride, hit, cnt);
+      if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
+        uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
+        for (int off = 32; off > 0; off >>= 1) {
+          db = max(db, (uint32_t)__shfl_xor((int)db, off));
+          dt = max(dt, (uint32_t)__shfl_xor((int)dt, off));
+        }
+        // lanes that are not live did not take part: the maxima over the active lanes are what counts,
+        // and every active lane holds them now; the first active lane books them
+        const unsigned long long act = __ballot(1);
+        if (lane == (uint32_t)__ffsll((long long)act) - 1u) {
+          slot_boxes += 64ull * db;
+          slot_tris += 64ull * dt;
+        }
+      }
       if (!in_shadow) {
         if (!found) {
           if (FUSED) finalize_pixel(fp, black() + black(), p, rgba8, rgba32f);  // unwrap_or(BLACK), color += it
@@ -647,16 +685,20 @@ __global__ __launch_bounds__(kBlock) void k_generation(DevScene sc, FrameParams 
   }
   if (STATS) {
     // wave reduction, then one atomic per wave and counter
-    unsigned long long b = cnt.boxes, t = cnt.tris, sh = n_shaded;
+    unsigned long long b = cnt.boxes, t = cnt.tris, sh = n_shaded, sb = slot_boxes, stt = slot_tris;
     for (int off = 32; off > 0; off >>= 1) {
       b += __shfl_down(b, off);
       t += __shfl_down(t, off);
       sh += __shfl_down(sh, off);
+      sb += __shfl_down(sb, off);
+      stt += __shfl_down(stt, off);
     }
     if (lane == 0) {
       atomicAdd(&counters->boxes, b);
       atomicAdd(&counters->tris, t);
       atomicAdd(&counters->shaded, sh);
+      atomicAdd(&counters->box_slots, sb);
+      atomicAdd(&counters->tri_slots, stt);
     }
   }
   if (MODE == kModePath) {

@@ -9,7 +9,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librayca_hip.so")
+LIB_PATH = os.environ.get("RAYCA_HIP_LIB") or os.path.join(_HERE, "csrc", "librayca_hip.so")
 _lib = None
 
 

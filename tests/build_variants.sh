@@ -1,0 +1,14 @@
+#!/bin/bash
+# builds experimental variants of the kernel library: tests/build_variants.sh name "-DFOO=1 ..." ...
+set -e
+cd "$(dirname "$0")/../rayca_amd/csrc"
+mkdir -p variants
+COMMON="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result"
+[ -f host_scene.o ] || g++ $COMMON -c host_scene.cpp -o host_scene.o -pthread
+while [ $# -gt 1 ]; do
+  name=$1; flags=$2; shift 2
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 $COMMON $flags -c kernels.hip -o variants/$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC variants/$name.o host_scene.o -o variants/librayca_$name.so -lpthread
+  rm variants/$name.o
+  echo built $name
+done
