@@ -37,6 +37,8 @@ struct DevScene {
   const float* tris;    // 9 floats per primitive slot (world-space v0,v1,v2)
   const PrimExt* ext;   // per primitive slot
   const uint32_t* tie_rank;  // nullptr: ties go to the lower slot; else to the lower rank (RAYCA_BUILDER_SAH)
+  const uint32_t* ref_leaf_of;    // RAYCA_BUILDER_SAH: slot -> reference leaf (nullptr otherwise)
+  const float4* ref_leaf_boxes;   // 2 x float4 per reference leaf: (min xyz, -), (max xyz, -)
   const DevMaterial* materials;
   const DevLight* lights;
   const DevTexture* textures;

@@ -330,8 +330,25 @@ void tlas_split(std::vector<TNode>& tn, int32_t self, std::vector<uint32_t>& bla
 struct DevBuilder {
   HostScene& s;
   std::vector<uint32_t> blas_base;  // first global primitive slot of each BLAS (TLAS order)
+  float pad_rel = 0.0f, pad_abs = 0.0f;  // RAYCA_BUILDER_SAH: conservative boxes (see build_host_scene)
 
-  static void put_box(DevNode& n, int side, const Box& b) {
+  void put_box(DevNode& n, int side, const Box& b0) {
+    Box b = b0;
+    if (pad_rel > 0.0f && b.a.x <= b.b.x) {
+      const float* lo[3] = {&b0.a.x, &b0.a.y, &b0.a.z};
+      const float* hi[3] = {&b0.b.x, &b0.b.y, &b0.b.z};
+      float* plo[3] = {&b.a.x, &b.a.y, &b.a.z};
+      float* phi[3] = {&b.b.x, &b.b.y, &b.b.z};
+      for (int k = 0; k < 3; ++k) {
+        const float m = fmaxf(fmaxf(fabsf(*lo[k]), fabsf(*hi[k])), *hi[k] - *lo[k]);
+        const float pad = m * pad_rel + pad_abs;
+        *plo[k] = *lo[k] - pad;
+        *phi[k] = *hi[k] + pad;
+      }
+    }
+    put_box_raw(n, side, b);
+  }
+  static void put_box_raw(DevNode& n, int side, const Box& b) {
     if (side == 0) {
       n.q[0] = b.a.x; n.q[1] = b.a.y; n.q[2] = b.a.z; n.q[3] = b.b.x; n.q[4] = b.b.y; n.q[5] = b.b.z;
     } else {
@@ -631,6 +648,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   std::vector<Box> blas_root(blas.size());
   // reference order of every primitive inside its BLAS (needed by both builders: it is the tie rule)
   std::vector<std::vector<uint32_t>> ref_prims(blas.size());
+  std::vector<std::vector<RefNode>> ref_nodes(blas.size());
   auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<RefNode>& nodes) {
     BlasBuilder bb{&s, &order, use_bvh ? 255u : 0u, par_levels + 1, seed_origin};
     std::vector<BuildNode> arena(1);
@@ -644,8 +662,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   for (size_t m = 0; m < blas.size(); ++m) {
     if (builder == RAYCA_BUILDER_SAH) {
       ref_prims[m] = blas[m].prims;
-      std::vector<RefNode> ref_nodes;
-      build_blas(m, true, ref_prims[m], ref_nodes);   // the reference's order, for ties only
+      build_blas(m, true, ref_prims[m], ref_nodes[m]);   // the reference's tree: tie order + candidate filter
       build_blas(m, false, blas[m].prims, blas[m].nodes);
     } else {
       build_blas(m, true, blas[m].prims, blas[m].nodes);
@@ -657,12 +674,23 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   if (!blas.empty()) tlas_split(tn, 0, blas_order, blas_root, 0, (uint32_t)blas.size());
   // store BLASes in TLAS order so that a TLAS range [offset, offset+count) indexes s.blas directly
   s.blas.clear();
-  std::vector<uint32_t> ref_rank;  // flatten index -> slot in the reference's global order
+  std::vector<uint32_t> ref_rank;       // flatten index -> slot in the reference's global order
+  std::vector<uint32_t> ref_leaf_flat;  // flatten index -> reference leaf
+  s.ref_leaf_boxes.clear();
   if (builder == RAYCA_BUILDER_SAH) {
     ref_rank.assign(s.prims.size(), 0);
+    ref_leaf_flat.assign(s.prims.size(), 0);
     uint32_t slot = 0;
-    for (uint32_t b : blas_order)
+    for (uint32_t b : blas_order) {
       for (uint32_t pi : ref_prims[b]) ref_rank[pi] = slot++;
+      for (const RefNode& rn : ref_nodes[b]) {
+        if (rn.count == 0) continue;  // inner node or the unused slot 1
+        const uint32_t leaf = (uint32_t)(s.ref_leaf_boxes.size() / 8);
+        const float bx[8] = {rn.a.x, rn.a.y, rn.a.z, 0.0f, rn.b.x, rn.b.y, rn.b.z, 0.0f};
+        s.ref_leaf_boxes.insert(s.ref_leaf_boxes.end(), bx, bx + 8);
+        for (uint32_t i = rn.offset; i < rn.offset + rn.count; ++i) ref_leaf_flat[ref_prims[b][i]] = leaf;
+      }
+    }
   }
   for (uint32_t b : blas_order) s.blas.push_back(std::move(blas[b]));
 
@@ -672,6 +700,16 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   s.max_depth = 0;
   if (!s.blas.empty()) {
     DevBuilder db{s, {}};
+    if (builder == RAYCA_BUILDER_SAH) {
+      // This tree's boxes only have to be conservative (the reference-leaf filter decides candidacy):
+      // pad them by 2^-16 of their magnitude plus 2^-20 of the scene diagonal, two orders of magnitude
+      // above the rounding of the slab and triangle arithmetic, so that a triangle the ray hits is
+      // never lost because an enclosing box rounds the other way.
+      const F4 ext = as_vec(tn[0].bounds.b - tn[0].bounds.a);
+      const float diag = sqrtf(ext.x * ext.x + ext.y * ext.y + ext.z * ext.z);
+      db.pad_rel = 1.52587890625e-05f;
+      db.pad_abs = (diag == diag && diag < FLT_MAX) ? diag * 9.5367431640625e-07f : 0.0f;
+    }
     uint32_t base = 0;
     for (const HostBlas& bl : s.blas) {
       db.blas_base.push_back(base);
@@ -685,9 +723,14 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     s.root_ref = db.emit_tlas(tn, 0, need);
     s.max_depth = need;
     s.tie_rank.clear();
+    s.ref_leaf_of.clear();
     if (builder == RAYCA_BUILDER_SAH) {
       s.tie_rank.resize(s.prim_order.size());
-      for (size_t slot = 0; slot < s.prim_order.size(); ++slot) s.tie_rank[slot] = ref_rank[s.prim_order[slot]];
+      s.ref_leaf_of.resize(s.prim_order.size());
+      for (size_t slot = 0; slot < s.prim_order.size(); ++slot) {
+        s.tie_rank[slot] = ref_rank[s.prim_order[slot]];
+        s.ref_leaf_of[slot] = ref_leaf_flat[s.prim_order[slot]];
+      }
     }
   }
   return RAYCA_OK;

@@ -91,6 +91,11 @@ struct HostScene {
   std::vector<uint32_t> prim_order; // slot -> flatten index
   uint32_t max_depth = 0;           // stack entries a traversal can have pending at once
   std::vector<uint32_t> tie_rank;   // RAYCA_BUILDER_SAH only: slot -> position in the reference's order
+  // RAYCA_BUILDER_SAH only: the reference tree's leaves.  A triangle is a candidate of the reference
+  // iff the slab test passes for its reference LEAF box (every ancestor box contains the leaf box and
+  // the slab arithmetic is monotone in the box corners, so the ancestors pass whenever the leaf does).
+  std::vector<float> ref_leaf_boxes;   // 8 floats per leaf: min xyz, pad, max xyz, pad
+  std::vector<uint32_t> ref_leaf_of;   // slot -> reference leaf index
 };
 
 // Returns RAYCA_OK or an error code with `err` filled.

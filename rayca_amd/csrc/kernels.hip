@@ -112,6 +112,17 @@ __device__ __forceinline__ bool tie_before(const DevScene& sc, uint32_t a, uint3
   return a < b;
 }
 
+// RAYCA_BUILDER_SAH: the reference only ever tests triangle i if the slab test passes for every box
+// above it in ITS tree; those boxes are nested and the slab arithmetic is monotone in the corners, so
+// that is equivalent to the slab test of the reference LEAF that holds i (bvh/blas.rs:136-139).
+__device__ __forceinline__ bool reference_candidate(const DevScene& sc, uint32_t i, const DRay& r) {
+  if (!sc.ref_leaf_of) return true;
+  const float4* b = sc.ref_leaf_boxes + 2ull * sc.ref_leaf_of[i];
+  const float4 lo = b[0], hi = b[1];
+  float tmin;
+  return slab(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, r, tmin);
+}
+
 struct LaneCounters {
   uint32_t boxes = 0, tris = 0;
 };
@@ -177,7 +188,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
         if (STATS) cnt.tris++;
         float t, u, v;
         if (tri_test(v0, v1, v2, r, t, u, v)) {
-          if (t < hit.t || (t == hit.t && tie_before(sc, i, hit.prim))) {
+          if ((t < hit.t || (t == hit.t && tie_before(sc, i, hit.prim))) && reference_candidate(sc, i, r)) {
             hit.t = t;
             hit.prim = i;
             hit.u = u;

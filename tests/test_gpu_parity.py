@@ -304,3 +304,56 @@ def test_tiles_reassemble_to_the_full_frame(cornell):
             assert st["rows_rendered"] == len(rows) == tile.shape[0]
             frame[rows] = tile
         assert_exact(frame, full)
+
+
+# ---- RAYCA_BUILDER_SAH: a different tree, the reference's candidates and tie order --------------------
+@pytest.mark.parametrize("name", ["box", "cornell", "soup", "atrium"])
+def test_sah_builder_is_exact_against_the_oracle(gpu, name):
+    """The SAH tree (empty-seeded candidate boxes) must give the reference's pixels bit for bit: a hit is
+    accepted only if the reference's own leaf box passes the slab test, depth ties go to the reference's
+    primitive order."""
+    desc = {"box": lambda: flatten(scenes.box_scene()), "cornell": lambda: flatten(scenes.cornell_scene()),
+            "soup": lambda: flatten(scenes.soup_scene(20000, extent=0.03)), "atrium": lambda: flatten(scenes.atrium_scene(detail=3))}[name]()
+    ds = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
+    orc = ol.OracleScene(desc, Config(), build=ol.BUILD_BINNED)
+    w, h = (320, 180) if name != "soup" else (384, 384)
+    for trav in (abi.TRAVERSAL_ORDERED, abi.TRAVERSAL_EXHAUSTIVE):
+        _, f32, _ = ds.render(FLAT, w, h, traversal=trav)
+        _, of32, _ = orc.render(FLAT, w, h)
+        assert_exact(f32, of32)
+    cfg = Config(max_depth=1)
+    u8, f32, _ = ds.render(cfg, w, h)
+    ou8, of32, _ = orc.render(cfg, w, h)
+    ok = ~(np.isnan(f32) | np.isnan(of32))
+    assert np.array_equal(np.isnan(f32), np.isnan(of32))
+    assert np.abs(np.where(ok, f32 - of32, 0)).max() <= TOL
+    # hit records: same primitive (compared in flatten order), same t and barycentrics
+    g = np.load(os.path.join(G, "box_256.npz" if name == "box" else "cornell_128x72.npz"))
+    rays = g["rays"] if name in ("box", "cornell") else None
+    if rays is not None:
+        t, prim, uv, _ = ds.trace_rays(rays)
+        ot, oprim, ouv, _ = orc.trace_rays(rays)
+        order, oorder = ds.primitive_order(), orc.primitive_order()
+        hit = prim != abi.NONE
+        assert np.array_equal(hit, oprim != abi.NONE)
+        assert np.array_equal(order[prim[hit]], oorder[oprim[hit]])
+        assert np.array_equal(bits(t), bits(ot)) and np.array_equal(bits(uv), bits(ouv))
+
+
+def test_sah_and_reference_builders_agree_at_full_size(gpu):
+    """BASELINE configs[2] geometry at 1920x1080: the two trees must produce the same frame (GPU only;
+    the oracle would need minutes per frame on the reference's tree)."""
+    desc = flatten(scenes.atrium_scene())
+    a = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
+    b = DeviceScene(desc, Config(), builder=abi.BUILDER_REFERENCE)
+    assert a.info()["node_count"] > 50 * b.info()["node_count"]   # the reference's tree barely splits
+    _, fa, _ = a.render(FLAT, 1920, 1080)
+    _, fb, _ = b.render(FLAT, 1920, 1080)
+    assert_exact(fa, fb)
+    _, fa, _ = a.render(FLAT, 1920, 1080, traversal=abi.TRAVERSAL_EXHAUSTIVE)
+    assert_exact(fa, fb)
+    cfg = Config(max_depth=1)
+    ua, fa, sa = a.render(cfg, 1920, 1080, collect_stats=True)
+    ub, fb, sb = b.render(cfg, 1920, 1080, collect_stats=True)
+    assert np.array_equal(bits(fa), bits(fb)) and np.array_equal(ua, ub)
+    assert sa["rays_shadow"] == sb["rays_shadow"] and sa["hits_shaded"] == sb["hits_shaded"]
