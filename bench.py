@@ -36,6 +36,9 @@ def workload_config(name):
     if name == "atrium":
         return dict(label="sponza-STAND-IN procedural atrium 271,568 tris, 1920x1080, primary + 1 shadow ray (Pathtracer max_depth=1, NEE, 1 point light), 1 spp",
                     width=1920, height=1080, cfg=Config(max_depth=1))
+    if name == "atrium4k":
+        return dict(label="sponza-STAND-IN procedural atrium 271,568 tris, 3840x2160, 4-bounce path trace (Pathtracer max_depth=5, NEE + cosine), 1 spp",
+                    width=3840, height=2160, cfg=Config(max_depth=5))
     if name == "soup":
         return dict(label="synthetic soup 1,048,576 random tris (seed 0x5EED0001), 4096x4096, primary rays only (Flat), 1 spp",
                     width=4096, height=4096, cfg=Config(integrator=IntegratorStrategy.Flat))
@@ -70,11 +73,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)   # one process per GPU; the modulo only matters for rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # RCCL ("nccl") over xGMI is the real path; RAYCA_DIST_BACKEND=gloo only exists to rehearse the
+    # N>1 control flow on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
+    backend = os.environ.get("RAYCA_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as g
     if rank == 0:
@@ -86,10 +97,10 @@ def main():
 
     wl = workload_config(args.workload)
     cfg, W, H = wl["cfg"], wl["width"], wl["height"]
-    scene = scenes.WORKLOADS[args.workload]["scene"]()
+    scene = scenes.WORKLOADS["atrium" if args.workload == "atrium4k" else args.workload]["scene"]()
     desc = flatten(scene)
     builder = abi.BUILDER_SAH if args.builder == "sah" else abi.BUILDER_REFERENCE
-    ds = DeviceScene(desc, cfg, device=local_rank, builder=builder)
+    ds = DeviceScene(desc, cfg, device=dev_index, builder=builder)
     info = ds.info()
     tile = tile_of(rank, world, args.band_rows)
     my_rows = int(rows_of(tile, H).numel())
@@ -99,7 +110,13 @@ def main():
     def step(want_stats=False):
         with torch.cuda.stream(stream):
             st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=want_stats)
-            frame = gather_frame(out, H, args.band_rows) if world > 1 else out
+            if world == 1:
+                frame = out
+            elif backend == "nccl":
+                frame = gather_frame(out, H, args.band_rows)
+            else:  # rehearsal: gloo gathers host tensors
+                stream.synchronize()
+                frame = gather_frame(out.cpu(), H, args.band_rows)
         return st, frame
 
     # instrumented run: rays + algorithmic bytes of this rank's launch (not timed)
@@ -128,7 +145,8 @@ def main():
         tms.append(st["trace_kernel_ms"] / max(st["trace_kernel_launches"], 1))
     trace_ms = float(np.mean(tms))
 
-    t = torch.tensor([elapsed, float(rays_rank), float(algo_bytes), trace_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(rays_rank), float(algo_bytes), trace_ms], dtype=torch.float64,
+                     device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,7 +180,7 @@ def main():
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
-                   "frame_gather": "torch.distributed.gather (RCCL)" if world > 1 else "none"},
+                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "none")},
         "roofline": {"bound": "hbm", "kernel": "k_generation (generation 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4),

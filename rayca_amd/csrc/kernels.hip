@@ -56,6 +56,26 @@ __device__ __forceinline__ bool slab(float ax, float ay, float az, float bx, flo
   return tmax >= tmin && tmax > 0.0f;
 }
 
+// Conservative box test for trees whose boxes are padded (RAYCA_BUILDER_SAH): t = b*rd - o*rd with one
+// FMA per plane.  Not the reference's rounding -- it does not have to be: in that mode a triangle is a
+// candidate iff the reference's own leaf box passes `slab` (reference_candidate), this test only steers
+// the search and the padding of the boxes dominates its rounding error.
+struct FastRay {
+  float rdx, rdy, rdz, ox, oy, oz;  // rd and -(o*rd)
+};
+__device__ __forceinline__ FastRay make_fast(const DRay& r) {
+  return FastRay{r.rd.x, r.rd.y, r.rd.z, -(r.o.x * r.rd.x), -(r.o.y * r.rd.y), -(r.o.z * r.rd.z)};
+}
+__device__ __forceinline__ bool slab_fast(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
+  const float t1x = __fmaf_rn(ax, f.rdx, f.ox), t2x = __fmaf_rn(bx, f.rdx, f.ox);
+  const float t1y = __fmaf_rn(ay, f.rdy, f.oy), t2y = __fmaf_rn(by, f.rdy, f.oy);
+  const float t1z = __fmaf_rn(az, f.rdz, f.oz), t2z = __fmaf_rn(bz, f.rdz, f.oz);
+  const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+  const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+  tmin_out = tmin;
+  return tmax >= tmin && tmax > 0.0f;
+}
+
 // Triangle::intersects  rayca-geometry/src/triangle.rs:84-159 on world-space vertices (identical
 // bits to `trs * vertex`, computed once on the host with the same operation sequence).
 __device__ __forceinline__ bool tri_test(F4 v0, F4 v1, F4 v2, const DRay& r, float& t_out, float& u_out, float& v_out) {
@@ -141,8 +161,9 @@ constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index
 // Structure: "while-while" -- all lanes of the wave first descend inner nodes until each holds a leaf
 // (or has finished), then the leaf lanes run the triangle tests together, so the expensive leaf code
 // is not serialised against node steps of other lanes.
-template <bool ORDERED, bool STATS>
+template <bool ORDERED, bool STATS, bool FAST>
 __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, uint32_t* stack, uint32_t stride, DHit& hit, LaneCounters& cnt) {
+  const FastRay fr = make_fast(r);
   hit.t = INFINITY;
   hit.prim = RAYCA_NONE;
   hit.u = hit.v = 0.0f;
@@ -159,8 +180,14 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
       const float4* np = sc.nodes + 4ull * cur;
       const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
       float tl, tr;
-      bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
-      bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+      bool hl, hr;
+      if (FAST) {
+        hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
+        hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
+      } else {
+        hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
+        hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+      }
       if (STATS) cnt.boxes += 2;
       const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
       if (ORDERED) {
@@ -528,7 +555,7 @@ __device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const Frame
 //   primary ray -> shade -> [NEE shadow ray]* -> bounce sample -> done
 // so the traversal loop is instantiated once per kernel and the registers that must survive it are
 // the ray, the hit, the compact ShadeCtx and a few colours.
-template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED>
+template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED, bool FAST>
 __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
                                                        PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
@@ -588,7 +615,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
     while (live) {
       DHit hit;
       const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
-      const bool found = trace<ORDERED, STATS>(sc, ray, t_stop, stack, stride, hit, cnt);
+      const bool found = trace<ORDERED, STATS, FAST>(sc, ray, t_stop, stack, stride, hit, cnt);
       if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
         uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
         for (int off = 32; off > 0; off >>= 1) {
@@ -763,7 +790,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers 
   else accum[p] = as_f4(acc);
 }
 
-template <bool ORDERED, bool STATS>
+template <bool ORDERED, bool STATS, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
                                                        TraceCounters* counters) {
   extern __shared__ uint32_t lds_stack[];
@@ -774,7 +801,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float*
     const float* r = rays + 6ull * i;
     const DRay ray = make_ray(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
     DHit hit;
-    const bool found = trace<ORDERED, STATS>(sc, ray, FLT_MAX, stack, kBlock, hit, cnt);
+    const bool found = trace<ORDERED, STATS, FAST>(sc, ray, FLT_MAX, stack, kBlock, hit, cnt);
     t_out[i] = found ? hit.t : FLT_MAX;
     prim_out[i] = found ? hit.prim : RAYCA_NONE;
     uv_out[2 * i] = found ? hit.u : 0.0f;
