@@ -104,19 +104,35 @@ def main():
     info = ds.info()
     tile = tile_of(rank, world, args.band_rows)
     my_rows = int(rows_of(tile, H).numel())
-    out = torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.Stream(dev)  # render kernels and the frame gather share this stream
+    # two output buffers: the gather of frame i (comm stream) overlaps the render of frame i+1
+    outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    out = outs[0]
+    stream = torch.cuda.Stream(dev)       # render kernels
+    comm = torch.cuda.Stream(dev)         # frame gather (RCCL)
+    ev_render = [torch.cuda.Event() for _ in range(2)]
+    ev_gather = [torch.cuda.Event() for _ in range(2)]
+    for e in ev_gather:
+        e.record(comm)
+    counter = [0]
 
     def step(want_stats=False):
+        i = counter[0] & 1
+        counter[0] += 1
+        buf = outs[i]
         with torch.cuda.stream(stream):
-            st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=want_stats)
-            if world == 1:
-                frame = out
-            elif backend == "nccl":
-                frame = gather_frame(out, H, args.band_rows)
+            stream.wait_event(ev_gather[i])   # the previous gather out of this buffer has finished
+            st = ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=want_stats)
+            ev_render[i].record(stream)
+        if world == 1:
+            return st, buf
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_render[i])
+            if backend == "nccl":
+                frame = gather_frame(buf, H, args.band_rows)
             else:  # rehearsal: gloo gathers host tensors
-                stream.synchronize()
-                frame = gather_frame(out.cpu(), H, args.band_rows)
+                comm.synchronize()
+                frame = gather_frame(buf.cpu(), H, args.band_rows)
+            ev_gather[i].record(comm)
         return st, frame
 
     # instrumented run: rays + algorithmic bytes of this rank's launch (not timed)

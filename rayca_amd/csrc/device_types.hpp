@@ -21,6 +21,17 @@ struct DevTexture {
   uint64_t byte_offset;
 };
 
+// Sphere primitive (rayca-geometry/src/sphere.rs:38-44) with everything its tests and its normal need,
+// all derived on the host with the reference's operation order.
+struct DevSphere {
+  float center[4];        // model-space Point3
+  float radius2, pad0, pad1, pad2;
+  float translation[4], rotation[4], scale[4];  // WORLD Trs of the node (primitive.rs:95-101)
+  float inv_rotation[4], inv_scale[4];           // Inversed<&Trs>: conj(R), reciprocal(S)  (trs.rs:320-331)
+  float inv_mat4[16];     // Mat4::from(&Inversed<Trs>) row-major (trs.rs:372-381): world point -> model point
+  float normal_mat[12];   // rows of transpose(Mat3::from(&inverse)) padded to 4 (primitive.rs:183-190)
+};
+
 struct DevLight {
   uint32_t kind, material;
   float intensity, pad;
@@ -41,6 +52,7 @@ struct DevScene {
   const float4* ref_leaf_boxes;   // 2 x float4 per reference leaf: (min xyz, -), (max xyz, -)
   const DevMaterial* materials;
   const DevLight* lights;
+  const DevSphere* spheres;
   const DevTexture* textures;
   const uint8_t* image_bytes;
   uint32_t material_count, light_count, texture_count, prim_count;

@@ -104,6 +104,47 @@ __device__ __forceinline__ bool tri_test(F4 v0, F4 v1, F4 v2, const DRay& r, flo
   return true;
 }
 
+// Sphere::intersects  rayca-geometry/src/sphere.rs:101-163: the ray is taken to model space by
+// Inversed<&Trs> (translate -T, rotate R^-1, scale 1/S; trs.rs:405-414), intersected, and the hit point is
+// brought back by the world Trs.  A sphere occupies one primitive slot whose first float is NaN and
+// whose second float carries the sphere index.
+__device__ __forceinline__ DRay sphere_local_ray(const DevSphere& sp, const DRay& r) {
+  F4 o = r.o + (-f4(sp.translation[0], sp.translation[1], sp.translation[2], 0.0f));  // Ray::translate
+  F4 d = r.d;
+  const F4 iq = f4(sp.inv_rotation[0], sp.inv_rotation[1], sp.inv_rotation[2], sp.inv_rotation[3]);
+  d = rotate(d, iq);  // Ray::rotate
+  o = point_rotate(o, iq);
+  o.w = 1.0f;
+  const F4 is = f4(sp.inv_scale[0], sp.inv_scale[1], sp.inv_scale[2], sp.inv_scale[3]);
+  d = d * is;  // Ray::scale
+  o = point_scale(o, is);
+  DRay l;
+  l.o = o;
+  l.d = d;
+  l.rd = reciprocal(d);
+  return l;
+}
+__device__ __forceinline__ bool sphere_test(const DevSphere& sp, const DRay& r, float& t_out) {
+  const DRay l = sphere_local_ray(sp, r);
+  const F4 center = f4(sp.center[0], sp.center[1], sp.center[2], sp.center[3]);
+  const float a = dot(l.d, l.d);
+  const F4 c_to_r = as_vec(l.o - center);
+  const float b = dot(c_to_r, l.d);
+  const float c = dot(c_to_r, c_to_r) - sp.radius2;
+  const float det = b * b - a * c;
+  if (det < 0.0f) return false;
+  const float det_sqrt = sqrtf(det);
+  const float t0 = (-b + det_sqrt) / a;
+  const float t1 = (-b - det_sqrt) / a;
+  if (t0 < 0.0f && t1 < 0.0f) return false;
+  float t;
+  if (t0 >= 0.0f && t1 >= 0.0f) t = fminf(t0, t1);
+  else if (t0 >= 0.0f) t = t0;
+  else t = t1;
+  t_out = t;
+  return true;
+}
+
 // World-space triangle i: nine f32, 36-B stride, in leaf order.  (Compile with -DRAYCA_TRI_SOA to
 // read nine SoA planes instead -- kept only for the layout A/B in DESIGN.md section 3.)
 struct __attribute__((packed, aligned(4))) Tri9 {
@@ -161,7 +202,7 @@ constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index
 // Structure: "while-while" -- all lanes of the wave first descend inner nodes until each holds a leaf
 // (or has finished), then the leaf lanes run the triangle tests together, so the expensive leaf code
 // is not serialised against node steps of other lanes.
-template <bool ORDERED, bool STATS, bool FAST>
+template <bool ORDERED, bool STATS, bool FAST, bool SPH>
 __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, uint32_t* stack, uint32_t stride, DHit& hit, LaneCounters& cnt) {
   const FastRay fr = make_fast(r);
   hit.t = INFINITY;
@@ -214,7 +255,14 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
         load_tri(sc, i, v0, v1, v2);
         if (STATS) cnt.tris++;
         float t, u, v;
-        if (tri_test(v0, v1, v2, r, t, u, v)) {
+        bool got;
+        if (SPH && v0.x != v0.x) {  // sphere slot
+          u = v = 0.0f;
+          got = sphere_test(sc.spheres[__float_as_uint(v0.y)], r, t);
+        } else {
+          got = tri_test(v0, v1, v2, r, t, u, v);
+        }
+        if (got) {
           if ((t < hit.t || (t == hit.t && tie_before(sc, i, hit.prim))) && reference_candidate(sc, i, r)) {
             hit.t = t;
             hit.prim = i;
@@ -307,13 +355,17 @@ struct ShadeCtx {
 
 // get_color (primitive.rs:142-148) always; the rest only when `full` (Pathtracer).
 // barycentrics: u -> vertex 0, v -> vertex 1, 1-u-v -> vertex 2 (bvh/triangle.rs:34-38)
+template <bool SPH>
 __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, const DHit& hit, bool full, Color& color, bool& emissive,
                                           ShadeCtx& cx) {
   const PrimExt& e = sc.ext[hit.prim];
   const float bu = hit.u, bv = hit.v;
   const float w2 = 1.0f - bu - bv;
-  const Color geom_color = (load_color(e.color[2]) * w2 + load_color(e.color[0]) * bu) + load_color(e.color[1]) * bv;
-  const F2 uv{(e.uv[2][0] * w2 + e.uv[0][0] * bu) + e.uv[1][0] * bv, (e.uv[2][1] * w2 + e.uv[0][1] * bu) + e.uv[1][1] * bv};
+  const bool is_sphere = SPH && e.kind == RAYCA_GEOMETRY_SPHERE;
+  // BvhGeometry::get_color / get_uv: spheres are white with uv (0,0)  (primitive.rs:15-28)
+  const Color geom_color = is_sphere ? white() : (load_color(e.color[2]) * w2 + load_color(e.color[0]) * bu) + load_color(e.color[1]) * bv;
+  const F2 uv = is_sphere ? F2{0.0f, 0.0f}
+                          : F2{(e.uv[2][0] * w2 + e.uv[0][0] * bu) + e.uv[1][0] * bv, (e.uv[2][1] * w2 + e.uv[0][1] * bu) + e.uv[1][1] * bv};
   const DevMaterial m = (e.material != RAYCA_NONE && e.material < sc.material_count) ? sc.materials[e.material] : default_material();
   Color mc;  // Material::get_color  material/mod.rs:107-113
   if (m.kind == RAYCA_MATERIAL_PBR) mc = pbr_color(sc, m, uv);
@@ -323,8 +375,27 @@ __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, c
   emissive = m.emissive != 0u;
   if (!full) return;
   // normal: primitive.rs:172-182 -> material/mod.rs:125-139 -> pbr.rs:104-123
-  F4 normal = normalized(interp3(e.normal, bu, bv));
-  if (m.kind == RAYCA_MATERIAL_PBR && tex_valid(sc, m.normal_texture)) {
+  F4 normal;
+  F4 point = ray.o + ray.d * hit.t;  // Hit.point  triangle.rs:122
+  if (is_sphere) {  // primitive.rs:183-190 and sphere.rs:155-163
+    const DevSphere& sp = sc.spheres[e.node];
+    const DRay l = sphere_local_ray(sp, ray);
+    const F4 model_point = l.o + l.d * hit.t;
+    const Trs wt{f4(sp.translation[0], sp.translation[1], sp.translation[2], 0.0f), f4(sp.rotation[0], sp.rotation[1], sp.rotation[2], sp.rotation[3]),
+                 f4(sp.scale[0], sp.scale[1], sp.scale[2], 0.0f)};
+    point = trs_apply_point(wt, model_point);
+    const F4 hp = mat4_apply_point(reinterpret_cast<const float(*)[4]>(sp.inv_mat4), point);
+    const F4 mn = normalized(as_vec(hp - f4(sp.center[0], sp.center[1], sp.center[2], sp.center[3])));
+    const float* nm = sp.normal_mat;
+    float out[3] = {0.0f, 0.0f, 0.0f};
+    const float in[3] = {mn.x, mn.y, mn.z};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out[i] += nm[4 * i + j] * in[j];
+    normal = normalized(vec3(out[0], out[1], out[2]));
+  } else {
+    normal = normalized(interp3(e.normal, bu, bv));
+  }
+  if (!is_sphere && m.kind == RAYCA_MATERIAL_PBR && tex_valid(sc, m.normal_texture)) {
     const F4 tangent = normalized(interp3(e.tangent, bu, bv));
     const F4 bitangent = normalized(interp3(e.bitangent, bu, bv));
     F4 sn = premultiplied(sample_texture(sc, m.normal_texture, uv));
@@ -332,7 +403,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, c
     normal = normalized(mat3_apply(mat3_tbn(tangent, bitangent, normal), sn));
   }
   cx.normal = normal;
-  cx.point = ray.o + ray.d * hit.t;  // Hit.point  triangle.rs:122
+  cx.point = point;
   cx.view = -ray.d;                  // ray.rs:149-151
   cx.next_origin = cx.point + normal * kRayBias;  // hit.rs:164-171
   cx.kind = m.kind;
@@ -555,7 +626,7 @@ __device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const Frame
 //   primary ray -> shade -> [NEE shadow ray]* -> bounce sample -> done
 // so the traversal loop is instantiated once per kernel and the registers that must survive it are
 // the ray, the hit, the compact ShadeCtx and a few colours.
-template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED, bool FAST>
+template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED, bool FAST, bool SPH>
 __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
                                                        PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
@@ -615,7 +686,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
     while (live) {
       DHit hit;
       const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
-      const bool found = trace<ORDERED, STATS, FAST>(sc, ray, t_stop, stack, stride, hit, cnt);
+      const bool found = trace<ORDERED, STATS, FAST, SPH>(sc, ray, t_stop, stack, stride, hit, cnt);
       if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
         uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
         for (int off = 32; off > 0; off >>= 1) {
@@ -639,7 +710,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
           n_shaded++;
           Color color;
           bool emissive;
-          shade_hit(sc, ray, hit, MODE == kModePath, color, emissive, cx);
+          shade_hit<SPH>(sc, ray, hit, MODE == kModePath, color, emissive, cx);
           if (MODE == kModeFlat) {  // Flat::trace  integrator/flat.rs:16-28
             if (FUSED) finalize_pixel(fp, black() + color, p, rgba8, rgba32f);
             else {
@@ -648,8 +719,11 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
             }
             live = false;
           } else if (collect_emissive && emissive) {  // pathtracer.rs:83-87
-            pb.direct[slot] = as_f4(color);
-            pb.state[slot] = kVertexEmissive;
+            if (FUSED) finalize_pixel(fp, black() + color, p, rgba8, rgba32f);
+            else {
+              pb.direct[slot] = as_f4(color);
+              pb.state[slot] = kVertexEmissive;
+            }
             live = false;
           } else {
             in_shadow = true;  // enter the NEE loop (possibly empty)
@@ -681,6 +755,12 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
         } else {
           // all direct samples done: Pathtracer::trace_impl tail  pathtracer.rs:89-105
           const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
+          if (FUSED) {
+            // single generation, single sample: Some(direct + BLACK) goes straight to the pixel
+            finalize_pixel(fp, black() + (direct + black()), p, rgba8, rgba32f);
+            live = false;
+            continue;
+          }
           pb.direct[slot] = as_f4(direct);
           if (depth < limit) {
             // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40
@@ -790,7 +870,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers 
   else accum[p] = as_f4(acc);
 }
 
-template <bool ORDERED, bool STATS, bool FAST>
+template <bool ORDERED, bool STATS, bool FAST, bool SPH>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
                                                        TraceCounters* counters) {
   extern __shared__ uint32_t lds_stack[];
@@ -801,7 +881,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float*
     const float* r = rays + 6ull * i;
     const DRay ray = make_ray(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
     DHit hit;
-    const bool found = trace<ORDERED, STATS, FAST>(sc, ray, FLT_MAX, stack, kBlock, hit, cnt);
+    const bool found = trace<ORDERED, STATS, FAST, SPH>(sc, ray, FLT_MAX, stack, kBlock, hit, cnt);
     t_out[i] = found ? hit.t : FLT_MAX;
     prim_out[i] = found ? hit.prim : RAYCA_NONE;
     uv_out[2 * i] = found ? hit.u : 0.0f;

@@ -177,6 +177,49 @@ RC_FN F4 mat3_apply(const Mat3& m, F4 v) {  // mat3.rs:216-232: accumulates from
 }
 RC_FN Mat3 mat3_tbn(F4 t, F4 b, F4 n) { return Mat3{{{t.x, b.x, n.x}, {t.y, b.y, n.y}, {t.z, b.z, n.z}}}; }
 
+// ---- Mat4, only what the sphere normal path needs (rayca-math/src/mat4.rs) -----------------------
+struct Mat4 {
+  float m[4][4];
+};
+RC_FN Mat4 mat4_identity() { return Mat4{{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}}; }
+RC_FN Mat4 mat4_mul(const Mat4& a, const Mat4& b) {  // mat4.rs:160-188: ordered 16-lane sum, 12 lanes zero
+  Mat4 r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = -0.0f;
+      for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j];
+      for (int k = 4; k < 16; ++k) s += 0.0f;
+      r.m[i][j] = s;
+    }
+  return r;
+}
+RC_FN Mat4 mat4_from_quat(F4 q) {  // mat4.rs:205-236
+  const Mat3 r3 = mat3_from_quat(q);
+  Mat4 r = mat4_identity();
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.m[i][j] = r3.m[i][j];
+  return r;
+}
+RC_FN Mat4 mat4_from_inverse_trs(const Trs& t) {  // trs.rs:372-381: S^-1 * (R^-1 * T^-1)
+  Mat4 s = mat4_identity();
+  const F4 is = reciprocal(t.scale);
+  s.m[0][0] *= is.x;
+  s.m[1][1] *= is.y;
+  s.m[2][2] *= is.z;
+  const Mat4 r = mat4_mul(mat4_from_quat(quat_conj(t.rotation)), mat4_identity());
+  Mat4 tr = mat4_identity();
+  tr.m[0][3] += -t.translation.x;
+  tr.m[1][3] += -t.translation.y;
+  tr.m[2][3] += -t.translation.z;
+  return mat4_mul(s, mat4_mul(r, tr));
+}
+RC_FN F4 mat4_apply_point(const float (*m)[4], F4 p) {  // impl_mul3!(Point3, Mat4)  mat4.rs:296-320
+  float ret[4];
+  for (int i = 0; i < 4; ++i) ret[i] = hsum(f4(m[i][0], m[i][1], m[i][2], m[i][3]) * p);
+  const float den = ret[3] != 0.0f ? ret[3] : 1.0f;
+  return point3(ret[0] / den, ret[1] / den, ret[2] / den);
+}
+
 // ---- Color (rayca-math/src/color/mod.rs) -------------------------------------------------------
 RC_FN Color rgba(float r, float g, float b, float a) { return Color{r, g, b, a}; }
 RC_FN Color black() { return Color{0.0f, 0.0f, 0.0f, 1.0f}; }

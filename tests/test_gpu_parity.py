@@ -357,3 +357,53 @@ def test_sah_and_reference_builders_agree_at_full_size(gpu):
     ub, fb, sb = b.render(cfg, 1920, 1080, collect_stats=True)
     assert np.array_equal(bits(fa), bits(fb)) and np.array_equal(ua, ub)
     assert sa["rays_shadow"] == sb["rays_shadow"] and sa["hits_shaded"] == sb["hits_shaded"]
+
+
+# ---- spheres (rayca-geometry/src/sphere.rs) -----------------------------------------------------------
+def _sphere_scene(with_boxes=False):
+    """rayca-soft/tests/gltf.rs:9-46 `sphere` (unit sphere, scale (1,2,1), at z=-1) and, with_boxes, the
+    sphere-over-cubes arrangement of `cube_over_plane` (gltf.rs:86-186)."""
+    from rayca_amd import Sphere
+    scene = Scene()
+    model = Model()
+    g = model.geometries.push(Sphere.unit())
+    mat = model.materials.push(PbrMaterial(color=(0.2, 0.6, 0.9, 1.0), roughness_factor=0.7))
+    p = model.primitives.push(Primitive(geometry=g, material=mat))
+    m = model.meshes.push(Mesh(primitives=[p]))
+    trs = Trs(translation=(-0.5, 2.0, -3.0)) if with_boxes else Trs(translation=(0.0, 0.0, -1.0), scale=(1.0, 2.0, 1.0))
+    model.root.children.append(model.nodes.push(Node(mesh=m, trs=trs)))
+    scene.push_model(model)
+    if with_boxes:
+        for shift in ((1.0, 1.0, -2.0), (0.0, 0.0, -1.0), (-1.5, 0.0, -4.0)):
+            n = scene.push_model(scenes.load_gltf(os.path.join(G, "box.gltf")))
+            scene.nodes[n].trs = Trs(translation=shift)
+        floor = scene.push_model(scenes.load_gltf(os.path.join(G, "box.gltf")))
+        scene.nodes[floor].trs = Trs(translation=(0.0, -1.0, 0.0), scale=(16.0, 0.125, 16.0))
+    scene.push_model(SoftRenderer.create_default_model())
+    return scene
+
+
+@pytest.mark.parametrize("with_boxes", [False, True])
+def test_spheres(gpu, with_boxes):
+    desc = flatten(_sphere_scene(with_boxes))
+    for builder in (abi.BUILDER_REFERENCE, abi.BUILDER_SAH):
+        ds = DeviceScene(desc, Config(), builder=builder)
+        orc = ol.OracleScene(desc, Config())
+        assert ds.info()["sphere_count"] == 1
+        _, f32, _ = ds.render(FLAT, 256, 256)
+        _, of32, _ = orc.render(FLAT, 256, 256)
+        assert_exact(f32, of32)
+        assert (f32[..., 2] > 0.8).sum() > 500   # the sphere is there
+        cfg = Config(max_depth=1)
+        u8, f32, st = ds.render(cfg, 256, 256, collect_stats=True)
+        ou8, of32, ost = orc.render(cfg, 256, 256)
+        assert_close(f32, of32, u8, ou8)
+        assert st["rays_shadow"] == ost["rays_shadow"]
+        if builder == abi.BUILDER_REFERENCE:
+            rs = np.random.RandomState(3)
+            o = rs.uniform(-4, 4, (256, 3)).astype(np.float32)
+            d = (rs.uniform(-1, 1, (256, 3)) - o * 0.3).astype(np.float32)
+            rays = np.concatenate([o, d], 1)
+            t, prim, uv, _ = ds.trace_rays(rays)
+            ot, oprim, ouv, _ = orc.trace_rays(rays)
+            assert np.array_equal(prim, oprim) and np.array_equal(bits(t), bits(ot))
