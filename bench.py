@@ -203,6 +203,12 @@ def main():
                      "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),
                      "hits_shaded": int(counted["hits_shaded"]), "frame_kernel_ms": round(float(np.mean(kms)), 4)},
     }
+    # HBM traffic cannot be read from inside this process: it comes from the committed rocprofv3 --pmc
+    # passes over this same workload (profiles/pmc_traffic_<workload>.json), per launch like `achieved`
+    pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
+    if world == 1 and args.builder == "sah" and os.path.exists(pmc):
+        result["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
+        result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(desc, cfg, W, H, args.cpu_seconds)
     print(json.dumps(result), flush=True)

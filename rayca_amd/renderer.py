@@ -49,8 +49,8 @@ class DeviceScene:
     """Owns a RaycaScene handle: the device-resident scene + BVH (first half of draw, scene.rs:90-99)."""
 
     def __init__(self, desc: abi.SceneDesc, config: Optional[Config] = None, device: int = 0,
-                 builder: int = abi.BUILDER_REFERENCE):
-        self._lib = lib.load()
+                 builder: int = abi.BUILDER_REFERENCE, _lib=None):
+        self._lib = _lib or lib.load()  # _lib: an explicitly loaded build of the library (A/B experiments)
         self.desc = desc
         cfg = (config or Config()).to_abi()
         opts = abi.RaycaBuildOptions()
