@@ -44,7 +44,8 @@ struct DevLight {
 };
 
 struct DevScene {
-  const float4* nodes;  // 4 x float4 per DevNode
+  const float4* nodes;  // 4 x float4 per DevNode (binary tree)
+  const float4* nodes4; // 8 x float4 per DevNode4 (the same tree, 4-wide)
   const float* tris;    // 9 floats per primitive slot (world-space v0,v1,v2)
   const PrimExt* ext;   // per primitive slot
   const uint32_t* tie_rank;  // nullptr: ties go to the lower slot; else to the lower rank (RAYCA_BUILDER_SAH)
@@ -56,7 +57,7 @@ struct DevScene {
   const DevTexture* textures;
   const uint8_t* image_bytes;
   uint32_t material_count, light_count, texture_count, prim_count;
-  uint32_t root_ref;
+  uint32_t root_ref, root_ref4;
   float root_min[3], root_max[3];
   float cull_abs;  // absolute slack of the best-t cull (see trace())
   uint32_t tri_soa;  // 0: 36-B AoS triangles, 1: nine SoA planes of prim_count floats
@@ -75,6 +76,16 @@ struct FrameParams {
   uint32_t max_depth, russian_roulette, seed, spp, sample;
   float sub_x, sub_y;           // ix*step + offset, iy*step + offset of this sample (scene.rs:125-137)
   float inv_gamma;
+};
+
+// per-launch traversal workspace: the node stack lives in LDS up to `lds_entries` entries per lane
+// (entry-major, one 1-KiB row per entry and block) and spills to `ovf` beyond that
+struct TraceLaunch {
+  uint32_t* ovf;         // [entries over the LDS part][ovf_stride] dwords, or nullptr
+  uint32_t lds_entries;
+  uint32_t ovf_stride;   // total threads of the launch
+  uint32_t stats;        // collect box / triangle counters
+  uint32_t pad;
 };
 
 struct TraceCounters {

@@ -369,9 +369,13 @@ struct DevBuilder {
   // pushed entry is popped before the rest of the chain is entered.
   // a leaf range: one packed ref, or a chain of nodes re-testing the same box for > 64 primitives
   uint32_t emit_leaf(uint32_t first, uint32_t count, const Box& box, uint32_t& need) {
+    if (count == 0) {
+      need = 0;
+      return kNoChild;  // a model without primitives: nothing to visit
+    }
     if (count <= kLeafMaxPrims) {
       need = 0;
-      return leaf_ref(first, count == 0 ? 1 : count);
+      return leaf_ref(first, count);
     }
     // iterative: chains can be thousands of nodes long with the reference's coarse leaves
     const uint32_t head = new_node();
@@ -437,6 +441,102 @@ struct DevBuilder {
     s.dev_nodes[n].right = rr;
     need = 1 + std::max(nl, nr);
     return n;
+  }
+};
+
+// ---- 4-wide collapse ---------------------------------------------------------------------------
+// Each wide node adopts the grandchildren of a binary node (largest box first) until it has four
+// children.  Skipping a binary node skips its box test, which cannot change what the traversal finds:
+// a child's box is contained in its parent's and the slab arithmetic is monotone in the box corners,
+// so whenever a child box passes the test every box above it passes too.
+struct WideBuilder {
+  HostScene& s;
+  struct Kid {
+    uint32_t ref;
+    float b[6];  // min xyz, max xyz
+  };
+  static float kid_area(const Kid& k) {
+    const float ex = k.b[3] - k.b[0], ey = k.b[4] - k.b[1], ez = k.b[5] - k.b[2];
+    return ex * ey + ey * ez + ez * ex;
+  }
+  void kids_of(uint32_t bin, Kid out[2]) const {
+    const DevNode& n = s.dev_nodes[bin];
+    out[0].ref = n.left;
+    out[1].ref = n.right;
+    for (int i = 0; i < 6; ++i) {
+      out[0].b[i] = n.q[i];
+      out[1].b[i] = n.q[6 + i];
+    }
+  }
+  uint32_t build(uint32_t bin_ref, uint32_t& need) {
+    if ((bin_ref & kLeafFlag) || bin_ref == kNoChild) {
+      need = 0;
+      return bin_ref;
+    }
+    // iterative over an explicit work list would be needed for pathological depth only; the binary
+    // chains for big leaves are collapsed 3 links at a time here
+    Kid kids[4];
+    int k = 2;
+    kids_of(bin_ref, kids);
+    while (k < 4) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (int i = 0; i < k; ++i) {
+        if ((kids[i].ref & kLeafFlag) || kids[i].ref == kNoChild) continue;
+        const float a = kid_area(kids[i]);
+        if (best < 0 || a > best_area) {
+          best = i;
+          best_area = a;
+        }
+      }
+      if (best < 0) break;
+      Kid two[2];
+      kids_of(kids[best].ref, two);
+      // keep the left-to-right order of the binary tree (exhaustive mode visits children in index order)
+      for (int i = k; i > best + 1; --i) kids[i] = kids[i - 1];
+      kids[best] = two[0];
+      kids[best + 1] = two[1];
+      ++k;
+    }
+    const uint32_t idx = (uint32_t)s.dev_nodes4.size();
+    s.dev_nodes4.emplace_back();
+    uint32_t child_refs[4], child_need[4] = {0, 0, 0, 0};
+    uint32_t worst = 0;
+    for (int i = 0; i < k; ++i) {
+      uint32_t nd = 0;
+      child_refs[i] = build(kids[i].ref, nd);
+      child_need[i] = nd;
+      worst = std::max(worst, nd);
+    }
+    DevNode4& w = s.dev_nodes4[idx];
+    for (int i = 0; i < 4; ++i) {
+      if (i < k) {
+        for (int a = 0; a < 3; ++a) {
+          w.lo[a][i] = kids[i].b[a];
+          w.hi[a][i] = kids[i].b[3 + a];
+        }
+        w.child[i] = child_refs[i];
+      } else {
+        for (int a = 0; a < 3; ++a) {
+          w.lo[a][i] = FLT_MAX;
+          w.hi[a][i] = -FLT_MAX;
+        }
+        w.child[i] = kNoChild;
+      }
+      w.pad[i] = 0;
+    }
+    // pending entries: the nearest child is entered with k-1 siblings on the stack.  If all boxes are
+    // identical (the chains that split big leaves) the children are taken in index order, so child i
+    // is entered with k-1-i siblings pending.
+    bool same = true;
+    for (int i = 1; i < k && same; ++i) same = std::memcmp(kids[i].b, kids[0].b, sizeof kids[0].b) == 0;
+    if (same) {
+      need = 0;
+      for (int i = 0; i < k; ++i) need = std::max(need, (uint32_t)(k - 1 - i) + child_need[i]);
+    } else {
+      need = (uint32_t)(k - 1) + worst;
+    }
+    return idx;
   }
 };
 
@@ -722,6 +822,11 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     uint32_t need = 0;
     s.root_ref = db.emit_tlas(tn, 0, need);
     s.max_depth = need;
+    s.dev_nodes4.clear();
+    WideBuilder wb{s};
+    uint32_t need4 = 0;
+    s.root_ref4 = wb.build(s.root_ref, need4);
+    s.max_depth4 = need4;
     s.tie_rank.clear();
     s.ref_leaf_of.clear();
     if (builder == RAYCA_BUILDER_SAH) {

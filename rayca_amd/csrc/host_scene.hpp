@@ -41,6 +41,16 @@ struct DevNode {
   uint32_t left, right, pad0, pad1;
 };
 static_assert(sizeof(DevNode) == 64, "DevNode is 64 B");
+// 4-wide node, 128 B: the boxes of up to four children, SoA (min x[4], min y[4], min z[4], max x[4], ...),
+// then four packed child references; unused slots carry an inverted box and kNoChild.
+struct DevNode4 {
+  float lo[3][4];
+  float hi[3][4];
+  uint32_t child[4];
+  uint32_t pad[4];
+};
+static_assert(sizeof(DevNode4) == 128, "DevNode4 is 128 B");
+constexpr uint32_t kNoChild = 0x7FFFFFFFu;
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kLeafMaxPrims = 64;
 constexpr uint32_t kLeafFirstMask = 0x01FFFFFFu;
@@ -90,6 +100,10 @@ struct HostScene {
   F4 root_min, root_max;            // root box (tested before anything else, blas.rs:136-139)
   std::vector<uint32_t> prim_order; // slot -> flatten index
   uint32_t max_depth = 0;           // stack entries a traversal can have pending at once
+  // the same tree collapsed to 4-wide nodes (every other level skipped): what the kernels traverse
+  std::vector<DevNode4> dev_nodes4;
+  uint32_t root_ref4 = 0;
+  uint32_t max_depth4 = 0;          // pending stack entries for the 4-wide tree
   std::vector<uint32_t> tie_rank;   // RAYCA_BUILDER_SAH only: slot -> position in the reference's order
   // RAYCA_BUILDER_SAH only: the reference tree's leaves.  A triangle is a candidate of the reference
   // iff the slab test passes for its reference LEAF box (every ancestor box contains the leaf box and

@@ -188,95 +188,175 @@ struct LaneCounters {
   uint32_t boxes = 0, tris = 0;
 };
 
-constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index that never exists
+constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index that never exists (== kNoChild)
 
-// Closest hit along `r` (Tlas::intersects).  stack = this lane's LDS column, entries `stride` apart.
+// Per-lane node stack: the first `lds_entries` entries in LDS (entry-major: entry e of thread t at
+// lds[e*kBlock + t], so the 64 lanes of a wave always hit 64 different banks whatever their depths),
+// deeper entries in a global spill area laid out the same way.  The spill branch is cold: the LDS part
+// is sized from the tree on the host and covers every traversal of ordinary trees.
+struct NodeStack {
+  uint32_t* lds;
+  uint32_t* ovf;
+  uint32_t lds_entries, ovf_stride, sp;
+  __device__ __forceinline__ void push(uint32_t v) {
+    if (sp < lds_entries) lds[sp * kBlock] = v;
+    else ovf[(size_t)(sp - lds_entries) * ovf_stride] = v;
+    ++sp;
+  }
+  __device__ __forceinline__ uint32_t pop() {
+    if (sp == 0) return kTerminated;
+    --sp;
+    return sp < lds_entries ? lds[sp * kBlock] : ovf[(size_t)(sp - lds_entries) * ovf_stride];
+  }
+};
+__device__ __forceinline__ NodeStack make_stack(uint32_t* lds_base, const TraceLaunch& tl, uint32_t global_thread) {
+  NodeStack st;
+  st.lds = lds_base + threadIdx.x;
+  st.ovf = tl.ovf ? tl.ovf + global_thread : nullptr;
+  st.lds_entries = tl.lds_entries;
+  st.ovf_stride = tl.ovf_stride;
+  st.sp = 0;
+  return st;
+}
+
+// leaf: test primitives [first, first+count) -- shared by both node formats
+template <bool ORDERED, bool SPH>
+__device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uint32_t ref, float t_stop, bool stats, DHit& hit, float& limit,
+                                          LaneCounters& cnt) {
+  const uint32_t first = ref & kLeafFirstMask;
+  const uint32_t count = ((ref >> 25) & 63u) + 1u;
+  for (uint32_t i = first; i < first + count; ++i) {
+    F4 v0, v1, v2;
+    load_tri(sc, i, v0, v1, v2);
+    if (stats) cnt.tris++;
+    float t, u, v;
+    bool got;
+    if (SPH && v0.x != v0.x) {  // sphere slot
+      u = v = 0.0f;
+      got = sphere_test(sc.spheres[__float_as_uint(v0.y)], r, t);
+    } else {
+      got = tri_test(v0, v1, v2, r, t, u, v);
+    }
+    if (got) {
+      if ((t < hit.t || (t == hit.t && tie_before(sc, i, hit.prim))) && reference_candidate(sc, i, r)) {
+        hit.t = t;
+        hit.prim = i;
+        hit.u = u;
+        hit.v = v;
+        if (ORDERED) {
+          const float b = fminf(t, t_stop);
+          limit = b + fabsf(b) * 9.765625e-4f + sc.cull_abs;
+        }
+      }
+    }
+  }
+}
+
+// Closest hit along `r` (Tlas::intersects).
 //   ORDERED    front-to-back descent, subtrees whose entry distance exceeds the current best are
 //              skipped.  The winner is the (t, reference order) lexicographic minimum, which is what
 //              the reference's strict-< DFS returns (blas.rs:151,161,169).  The skip test carries a
 //              slack (relative 2^-10 plus sc.cull_abs) because a triangle's t and its box's slab
 //              entry are computed by different expressions and may disagree in the last bits.
-//   !ORDERED   visits exactly the boxes the reference visits (no culling).
+//   !ORDERED   visits every leaf the reference visits (no culling), children in the reference's order.
+//   FAST       conservative FMA slabs (only with the reference-leaf filter, see slab_fast).
+//   WIDE       4-wide nodes: one 128-B fetch tests four boxes and skips every other level of the
+//              binary tree (legal because a box that passes implies its ancestors pass).
 //   t_stop     any-hit early out: stop as soon as a hit with t < t_stop is found (shadow rays,
 //              "occluded iff closest depth < light distance", nee.rs:152-156).  FLT_MAX = never.
 // Structure: "while-while" -- all lanes of the wave first descend inner nodes until each holds a leaf
 // (or has finished), then the leaf lanes run the triangle tests together, so the expensive leaf code
 // is not serialised against node steps of other lanes.
-template <bool ORDERED, bool STATS, bool FAST, bool SPH>
-__device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, uint32_t* stack, uint32_t stride, DHit& hit, LaneCounters& cnt) {
+template <bool ORDERED, bool FAST, bool SPH, bool WIDE>
+__device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, NodeStack& st, bool stats, DHit& hit, LaneCounters& cnt) {
   const FastRay fr = make_fast(r);
   hit.t = INFINITY;
   hit.prim = RAYCA_NONE;
   hit.u = hit.v = 0.0f;
   float tmin;
-  if (STATS) cnt.boxes++;
-  uint32_t cur = sc.root_ref;
+  if (stats) cnt.boxes++;
+  uint32_t cur = WIDE ? sc.root_ref4 : sc.root_ref;
   if (!slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], r, tmin)) cur = kTerminated;
-  uint32_t sp = 0;
+  st.sp = 0;
   const bool any_hit = ORDERED && t_stop < FLT_MAX;
   float limit = INFINITY;  // cull bound (ORDERED only)
   if (any_hit) limit = t_stop + fabsf(t_stop) * 9.765625e-4f + sc.cull_abs;
   while (cur != kTerminated) {
     while (!(cur & kLeafFlag) && cur != kTerminated) {
-      const float4* np = sc.nodes + 4ull * cur;
-      const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-      float tl, tr;
-      bool hl, hr;
-      if (FAST) {
-        hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
-        hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
+      if (WIDE) {
+        const float4* np = sc.nodes4 + 8ull * cur;
+        const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
+        if (stats) cnt.boxes += 4;
+        float key[4];
+        uint32_t ref[4] = {__float_as_uint(cr.x), __float_as_uint(cr.y), __float_as_uint(cr.z), __float_as_uint(cr.w)};
+        const float ax[4] = {lx.x, lx.y, lx.z, lx.w}, ay[4] = {ly.x, ly.y, ly.z, ly.w}, az[4] = {lz.x, lz.y, lz.z, lz.w};
+        const float bx[4] = {hx.x, hx.y, hx.z, hx.w}, by[4] = {hy.x, hy.y, hy.z, hy.w}, bz[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float tc;
+          bool h = FAST ? slab_fast(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc) : slab(ax[c], ay[c], az[c], bx[c], by[c], bz[c], r, tc);
+          // an unused slot carries an inverted box, but (MAX - o) * rd overflows to +-inf for |rd| > 1
+          // and the slab test then "passes": the reference must be checked too
+          h = h && ref[c] != kTerminated;
+          if (ORDERED) h = h && tc <= limit;
+          // sort key: entry distance (ORDERED) or the child's index (reference order); misses sort last
+          key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
+        }
+        // 5-comparator network, strict `>` so equal keys keep their index order (the chains that
+        // split big leaves rely on it: see WideBuilder)
+#define RC_CE(i, j)                                  \
+  {                                                  \
+    const bool sw = key[i] > key[j];                 \
+    const float ka = sw ? key[j] : key[i];           \
+    const float kb = sw ? key[i] : key[j];           \
+    const uint32_t ra = sw ? ref[j] : ref[i];        \
+    const uint32_t rb = sw ? ref[i] : ref[j];        \
+    key[i] = ka; key[j] = kb; ref[i] = ra; ref[j] = rb; \
+  }
+        RC_CE(0, 1) RC_CE(2, 3) RC_CE(0, 2) RC_CE(1, 3) RC_CE(1, 2)
+#undef RC_CE
+        // farthest first, so the nearest pending sibling is popped first
+        if (key[3] < INFINITY) st.push(ref[3]);
+        if (key[2] < INFINITY) st.push(ref[2]);
+        if (key[1] < INFINITY) st.push(ref[1]);
+        cur = key[0] < INFINITY ? ref[0] : st.pop();
       } else {
-        hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
-        hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
-      }
-      if (STATS) cnt.boxes += 2;
-      const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-      if (ORDERED) {
-        hl = hl && tl <= limit;
-        hr = hr && tr <= limit;
-      }
-      if (hl && hr) {
-        const bool left_first = !ORDERED || tl <= tr;
-        stack[(sp++) * stride] = left_first ? rref : lref;
-        cur = left_first ? lref : rref;
-      } else if (hl) {
-        cur = lref;
-      } else if (hr) {
-        cur = rref;
-      } else {
-        cur = sp ? stack[(--sp) * stride] : kTerminated;
+        const float4* np = sc.nodes + 4ull * cur;
+        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        float tl, tr;
+        bool hl, hr;
+        if (FAST) {
+          hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
+          hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
+        } else {
+          hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
+          hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+        }
+        if (stats) cnt.boxes += 2;
+        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+        hl = hl && lref != kTerminated;  // empty subtree (a model without primitives)
+        hr = hr && rref != kTerminated;
+        if (ORDERED) {
+          hl = hl && tl <= limit;
+          hr = hr && tr <= limit;
+        }
+        if (hl && hr) {
+          const bool left_first = !ORDERED || tl <= tr;
+          st.push(left_first ? rref : lref);
+          cur = left_first ? lref : rref;
+        } else if (hl) {
+          cur = lref;
+        } else if (hr) {
+          cur = rref;
+        } else {
+          cur = st.pop();
+        }
       }
     }
     if (cur != kTerminated) {  // a leaf
-      const uint32_t first = cur & kLeafFirstMask;
-      const uint32_t count = ((cur >> 25) & 63u) + 1u;
-      for (uint32_t i = first; i < first + count; ++i) {
-        F4 v0, v1, v2;
-        load_tri(sc, i, v0, v1, v2);
-        if (STATS) cnt.tris++;
-        float t, u, v;
-        bool got;
-        if (SPH && v0.x != v0.x) {  // sphere slot
-          u = v = 0.0f;
-          got = sphere_test(sc.spheres[__float_as_uint(v0.y)], r, t);
-        } else {
-          got = tri_test(v0, v1, v2, r, t, u, v);
-        }
-        if (got) {
-          if ((t < hit.t || (t == hit.t && tie_before(sc, i, hit.prim))) && reference_candidate(sc, i, r)) {
-            hit.t = t;
-            hit.prim = i;
-            hit.u = u;
-            hit.v = v;
-            if (ORDERED) {
-              const float b = fminf(t, t_stop);
-              limit = b + fabsf(b) * 9.765625e-4f + sc.cull_abs;
-            }
-          }
-        }
-      }
+      test_leaf<ORDERED, SPH>(sc, r, cur, t_stop, stats, hit, limit, cnt);
       if (any_hit && hit.t < t_stop) break;
-      cur = sp ? stack[(--sp) * stride] : kTerminated;
+      cur = st.pop();
     }
   }
   return hit.prim != RAYCA_NONE;
@@ -626,14 +706,14 @@ __device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const Frame
 //   primary ray -> shade -> [NEE shadow ray]* -> bounce sample -> done
 // so the traversal loop is instantiated once per kernel and the registers that must survive it are
 // the ray, the hit, the compact ShadeCtx and a few colours.
-template <int MODE, bool GEN0, bool ORDERED, bool STATS, bool FUSED, bool FAST, bool SPH>
+template <int MODE, bool GEN0, bool ORDERED, bool FUSED, bool FAST, bool SPH, bool WIDE>
 __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
                                                        PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
-                                                       TraceCounters* counters) {
+                                                       TraceCounters* counters, TraceLaunch tl) {
   extern __shared__ uint32_t lds_stack[];
-  uint32_t* stack = lds_stack + threadIdx.x;
-  const uint32_t stride = kBlock;
+  NodeStack stack = make_stack(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
+  const bool STATS = tl.stats != 0u;
   const uint32_t lane = __lane_id();
   const uint32_t home = xcc_id();
   WorkCursor wc;
@@ -686,7 +766,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
     while (live) {
       DHit hit;
       const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
-      const bool found = trace<ORDERED, STATS, FAST, SPH>(sc, ray, t_stop, stack, stride, hit, cnt);
+      const bool found = trace<ORDERED, FAST, SPH, WIDE>(sc, ray, t_stop, stack, STATS, hit, cnt);
       if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
         uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
         for (int off = 32; off > 0; off >>= 1) {
@@ -870,18 +950,19 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers 
   else accum[p] = as_f4(acc);
 }
 
-template <bool ORDERED, bool STATS, bool FAST, bool SPH>
+template <bool ORDERED, bool FAST, bool SPH, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
-                                                       TraceCounters* counters) {
+                                                       TraceCounters* counters, TraceLaunch tl) {
   extern __shared__ uint32_t lds_stack[];
-  uint32_t* stack = lds_stack + threadIdx.x;
+  NodeStack stack = make_stack(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
+  const bool STATS = tl.stats != 0u;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   LaneCounters cnt;
   if (i < count) {
     const float* r = rays + 6ull * i;
     const DRay ray = make_ray(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
     DHit hit;
-    const bool found = trace<ORDERED, STATS, FAST, SPH>(sc, ray, FLT_MAX, stack, kBlock, hit, cnt);
+    const bool found = trace<ORDERED, FAST, SPH, WIDE>(sc, ray, FLT_MAX, stack, STATS, hit, cnt);
     t_out[i] = found ? hit.t : FLT_MAX;
     prim_out[i] = found ? hit.prim : RAYCA_NONE;
     uv_out[2 * i] = found ? hit.u : 0.0f;
