@@ -84,8 +84,6 @@ struct TraceLaunch {
   uint32_t* ovf;         // [entries over the LDS part][ovf_stride] dwords, or nullptr
   uint32_t lds_entries;
   uint32_t ovf_stride;   // total threads of the launch
-  uint32_t stats;        // collect box / triangle counters
-  uint32_t pad;
 };
 
 struct TraceCounters {

@@ -327,6 +327,9 @@ void tlas_split(std::vector<TNode>& tn, int32_t self, std::vector<uint32_t>& bla
 }
 
 // ---- device layout -------------------------------------------------------------------------------
+// Box of a slot that must never be entered (see WideBuilder): a zero-size box far away.
+constexpr float kNowhere = 1.0e18f;
+
 struct DevBuilder {
   HostScene& s;
   std::vector<uint32_t> blas_base;  // first global primitive slot of each BLAS (TLAS order)
@@ -334,6 +337,10 @@ struct DevBuilder {
 
   void put_box(DevNode& n, int side, const Box& b0) {
     Box b = b0;
+    if (!(b0.a.x <= b0.b.x)) {  // the inverted box of an empty BLAS: make it unhittable
+      b.a = point3(kNowhere, kNowhere, kNowhere);
+      b.b = b.a;
+    }
     if (pad_rel > 0.0f && b.a.x <= b.b.x) {
       const float* lo[3] = {&b0.a.x, &b0.a.y, &b0.a.z};
       const float* hi[3] = {&b0.b.x, &b0.b.y, &b0.b.z};
@@ -517,9 +524,12 @@ struct WideBuilder {
         }
         w.child[i] = child_refs[i];
       } else {
+        // Unused slot: a zero-size box far away.  (An inverted +-FLT_MAX box does NOT work: (MAX - o) * rd
+        // overflows to +-inf for |rd| > 1 and the slab test then passes.)  A point box passes only if the
+        // three axis distances are equal, and any overflow makes them unordered, so it is never entered.
         for (int a = 0; a < 3; ++a) {
-          w.lo[a][i] = FLT_MAX;
-          w.hi[a][i] = -FLT_MAX;
+          w.lo[a][i] = kNowhere;
+          w.hi[a][i] = kNowhere;
         }
         w.child[i] = kNoChild;
       }

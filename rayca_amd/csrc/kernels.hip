@@ -22,8 +22,11 @@ namespace rayca {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef RAYCA_MIN_WAVES_FLAT
+#define RAYCA_MIN_WAVES_FLAT 5
+#endif
 #ifndef RAYCA_MIN_WAVES
-#define RAYCA_MIN_WAVES 1
+#define RAYCA_MIN_WAVES 4
 #endif
 
 struct DRay {
@@ -194,23 +197,25 @@ constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index
 // lds[e*kBlock + t], so the 64 lanes of a wave always hit 64 different banks whatever their depths),
 // deeper entries in a global spill area laid out the same way.  The spill branch is cold: the LDS part
 // is sized from the tree on the host and covers every traversal of ordinary trees.
+template <bool SPILL>
 struct NodeStack {
   uint32_t* lds;
   uint32_t* ovf;
   uint32_t lds_entries, ovf_stride, sp;
   __device__ __forceinline__ void push(uint32_t v) {
-    if (sp < lds_entries) lds[sp * kBlock] = v;
+    if (!SPILL || sp < lds_entries) lds[sp * kBlock] = v;
     else ovf[(size_t)(sp - lds_entries) * ovf_stride] = v;
     ++sp;
   }
   __device__ __forceinline__ uint32_t pop() {
     if (sp == 0) return kTerminated;
     --sp;
-    return sp < lds_entries ? lds[sp * kBlock] : ovf[(size_t)(sp - lds_entries) * ovf_stride];
+    return (!SPILL || sp < lds_entries) ? lds[sp * kBlock] : ovf[(size_t)(sp - lds_entries) * ovf_stride];
   }
 };
-__device__ __forceinline__ NodeStack make_stack(uint32_t* lds_base, const TraceLaunch& tl, uint32_t global_thread) {
-  NodeStack st;
+template <bool SPILL>
+__device__ __forceinline__ NodeStack<SPILL> make_stack(uint32_t* lds_base, const TraceLaunch& tl, uint32_t global_thread) {
+  NodeStack<SPILL> st;
   st.lds = lds_base + threadIdx.x;
   st.ovf = tl.ovf ? tl.ovf + global_thread : nullptr;
   st.lds_entries = tl.lds_entries;
@@ -220,15 +225,15 @@ __device__ __forceinline__ NodeStack make_stack(uint32_t* lds_base, const TraceL
 }
 
 // leaf: test primitives [first, first+count) -- shared by both node formats
-template <bool ORDERED, bool SPH>
-__device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uint32_t ref, float t_stop, bool stats, DHit& hit, float& limit,
+template <bool ORDERED, bool SPH, bool STATS>
+__device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uint32_t ref, float t_stop, DHit& hit, float& limit,
                                           LaneCounters& cnt) {
   const uint32_t first = ref & kLeafFirstMask;
   const uint32_t count = ((ref >> 25) & 63u) + 1u;
   for (uint32_t i = first; i < first + count; ++i) {
     F4 v0, v1, v2;
     load_tri(sc, i, v0, v1, v2);
-    if (stats) cnt.tris++;
+    if (STATS) cnt.tris++;
     float t, u, v;
     bool got;
     if (SPH && v0.x != v0.x) {  // sphere slot
@@ -267,14 +272,14 @@ __device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uin
 // Structure: "while-while" -- all lanes of the wave first descend inner nodes until each holds a leaf
 // (or has finished), then the leaf lanes run the triangle tests together, so the expensive leaf code
 // is not serialised against node steps of other lanes.
-template <bool ORDERED, bool FAST, bool SPH, bool WIDE>
-__device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, NodeStack& st, bool stats, DHit& hit, LaneCounters& cnt) {
+template <bool ORDERED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS>
+__device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, NodeStack<SPILL>& st, DHit& hit, LaneCounters& cnt) {
   const FastRay fr = make_fast(r);
   hit.t = INFINITY;
   hit.prim = RAYCA_NONE;
   hit.u = hit.v = 0.0f;
   float tmin;
-  if (stats) cnt.boxes++;
+  if (STATS) cnt.boxes++;
   uint32_t cur = WIDE ? sc.root_ref4 : sc.root_ref;
   if (!slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], r, tmin)) cur = kTerminated;
   st.sp = 0;
@@ -286,7 +291,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
       if (WIDE) {
         const float4* np = sc.nodes4 + 8ull * cur;
         const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
-        if (stats) cnt.boxes += 4;
+        if (STATS) cnt.boxes += 4;
         float key[4];
         uint32_t ref[4] = {__float_as_uint(cr.x), __float_as_uint(cr.y), __float_as_uint(cr.z), __float_as_uint(cr.w)};
         const float ax[4] = {lx.x, lx.y, lx.z, lx.w}, ay[4] = {ly.x, ly.y, ly.z, ly.w}, az[4] = {lz.x, lz.y, lz.z, lz.w};
@@ -295,9 +300,6 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
         for (int c = 0; c < 4; ++c) {
           float tc;
           bool h = FAST ? slab_fast(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc) : slab(ax[c], ay[c], az[c], bx[c], by[c], bz[c], r, tc);
-          // an unused slot carries an inverted box, but (MAX - o) * rd overflows to +-inf for |rd| > 1
-          // and the slab test then "passes": the reference must be checked too
-          h = h && ref[c] != kTerminated;
           if (ORDERED) h = h && tc <= limit;
           // sort key: entry distance (ORDERED) or the child's index (reference order); misses sort last
           key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
@@ -332,10 +334,8 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
           hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
           hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
         }
-        if (stats) cnt.boxes += 2;
+        if (STATS) cnt.boxes += 2;
         const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-        hl = hl && lref != kTerminated;  // empty subtree (a model without primitives)
-        hr = hr && rref != kTerminated;
         if (ORDERED) {
           hl = hl && tl <= limit;
           hr = hr && tr <= limit;
@@ -354,7 +354,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
       }
     }
     if (cur != kTerminated) {  // a leaf
-      test_leaf<ORDERED, SPH>(sc, r, cur, t_stop, stats, hit, limit, cnt);
+      test_leaf<ORDERED, SPH, STATS>(sc, r, cur, t_stop, hit, limit, cnt);
       if (any_hit && hit.t < t_stop) break;
       cur = st.pop();
     }
@@ -706,14 +706,13 @@ __device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const Frame
 //   primary ray -> shade -> [NEE shadow ray]* -> bounce sample -> done
 // so the traversal loop is instantiated once per kernel and the registers that must survive it are
 // the ray, the hit, the compact ShadeCtx and a few colours.
-template <int MODE, bool GEN0, bool ORDERED, bool FUSED, bool FAST, bool SPH, bool WIDE>
-__global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
+template <int MODE, bool GEN0, bool ORDERED, bool FUSED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS>
+__global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
                                                        PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
                                                        TraceCounters* counters, TraceLaunch tl) {
   extern __shared__ uint32_t lds_stack[];
-  NodeStack stack = make_stack(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
-  const bool STATS = tl.stats != 0u;
+  NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
   const uint32_t lane = __lane_id();
   const uint32_t home = xcc_id();
   WorkCursor wc;
@@ -762,11 +761,14 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
     ns.quad = 0u;
     Color direct = black();
     uint32_t li = 0, k = 0, dim = 0;
+    // FUSED (Flat only): a lane that finishes leaves its pixel sum in `direct`; the gamma + quantise + store tail runs
+    // once per batch with the wave reconverged, not inside the divergent state machine
+    const bool has_pixel = live;
 
     while (live) {
       DHit hit;
       const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
-      const bool found = trace<ORDERED, FAST, SPH, WIDE>(sc, ray, t_stop, stack, STATS, hit, cnt);
+      const bool found = trace<ORDERED, FAST, SPH, WIDE, SPILL, STATS>(sc, ray, t_stop, stack, hit, cnt);
       if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
         uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
         for (int off = 32; off > 0; off >>= 1) {
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
       }
       if (!in_shadow) {
         if (!found) {
-          if (FUSED) finalize_pixel(fp, black() + black(), p, rgba8, rgba32f);  // unwrap_or(BLACK), color += it
+          if (FUSED) direct = black() + black();  // unwrap_or(BLACK), color += it
           else pb.state[slot] = kVertexNone;
           live = false;
         } else {
@@ -792,18 +794,15 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
           bool emissive;
           shade_hit<SPH>(sc, ray, hit, MODE == kModePath, color, emissive, cx);
           if (MODE == kModeFlat) {  // Flat::trace  integrator/flat.rs:16-28
-            if (FUSED) finalize_pixel(fp, black() + color, p, rgba8, rgba32f);
+            if (FUSED) direct = black() + color;
             else {
               pb.direct[slot] = as_f4(color);
               pb.state[slot] = kVertexEmissive;
             }
             live = false;
           } else if (collect_emissive && emissive) {  // pathtracer.rs:83-87
-            if (FUSED) finalize_pixel(fp, black() + color, p, rgba8, rgba32f);
-            else {
-              pb.direct[slot] = as_f4(color);
-              pb.state[slot] = kVertexEmissive;
-            }
+            pb.direct[slot] = as_f4(color);
+            pb.state[slot] = kVertexEmissive;
             live = false;
           } else {
             in_shadow = true;  // enter the NEE loop (possibly empty)
@@ -835,12 +834,6 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
         } else {
           // all direct samples done: Pathtracer::trace_impl tail  pathtracer.rs:89-105
           const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
-          if (FUSED) {
-            // single generation, single sample: Some(direct + BLACK) goes straight to the pixel
-            finalize_pixel(fp, black() + (direct + black()), p, rgba8, rgba32f);
-            live = false;
-            continue;
-          }
           pb.direct[slot] = as_f4(direct);
           if (depth < limit) {
             // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40
@@ -879,7 +872,11 @@ __global__ __launch_bounds__(kBlock, RAYCA_MIN_WAVES) void k_generation(DevScene
         }
       }
     }
-    if (MODE == kModePath) push_ray(want_bounce, next, out_rays, out_count);
+    if (FUSED) {
+      if (has_pixel) finalize_pixel(fp, direct, p, rgba8, rgba32f);
+    } else if (MODE == kModePath) {
+      push_ray(want_bounce, next, out_rays, out_count);
+    }
   }
   if (STATS) {
     // wave reduction, then one atomic per wave and counter
@@ -950,19 +947,18 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers 
   else accum[p] = as_f4(acc);
 }
 
-template <bool ORDERED, bool FAST, bool SPH, bool WIDE>
+template <bool ORDERED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS>
 __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
                                                        TraceCounters* counters, TraceLaunch tl) {
   extern __shared__ uint32_t lds_stack[];
-  NodeStack stack = make_stack(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
-  const bool STATS = tl.stats != 0u;
+  NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   LaneCounters cnt;
   if (i < count) {
     const float* r = rays + 6ull * i;
     const DRay ray = make_ray(point3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]));
     DHit hit;
-    const bool found = trace<ORDERED, FAST, SPH, WIDE>(sc, ray, FLT_MAX, stack, STATS, hit, cnt);
+    const bool found = trace<ORDERED, FAST, SPH, WIDE, SPILL, STATS>(sc, ray, FLT_MAX, stack, hit, cnt);
     t_out[i] = found ? hit.t : FLT_MAX;
     prim_out[i] = found ? hit.prim : RAYCA_NONE;
     uv_out[2 * i] = found ? hit.u : 0.0f;
