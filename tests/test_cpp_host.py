@@ -1,0 +1,166 @@
+"""The C++ host mirror (include/rayca.hpp) against the Python mirror (rayca_amd.model): the same scenes, built
+the way the reference's own tests build them (rayca-soft/tests/gltf.rs:10-83), must flatten to the same
+RaycaSceneDesc arrays, and on the GPU draw the same frame."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rayca_amd import abi, model as M
+from rayca_amd import Config, IntegratorStrategy, SoftRenderer, flatten
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_mirror(product_lib):
+    import __graft_entry__ as g
+    exe = g.build_cpp_host()
+    assert os.path.exists(exe)
+    return exe
+
+
+def _color(rgba):
+    return [((rgba >> s) & 0xFF) / 255.0 for s in (24, 16, 8, 0)]
+
+
+def triangle_scene():
+    model = M.Model()
+    tri = M.TriangleMesh.unit()
+    tri.colors = np.array([_color(0xFF0000FF), _color(0x00FF00FF), _color(0x0000FFFF)], np.float32)
+    g = model.geometries.push(tri)
+    p = model.primitives.push(M.Primitive(geometry=g))
+    m = model.meshes.push(M.Mesh(primitives=[p]))
+    n = model.nodes.push(M.Node(mesh=m, trs=M.Trs(translation=(0.0, -1.0, 0.0), scale=(1.0, 2.0, 1.0))))
+    model.root.children.append(n)
+    scene = M.Scene()
+    scene.push_model(model)
+    scene.push_model(M.create_default_model())
+    return scene
+
+
+def sphere_scene():
+    model = M.Model()
+    g = model.geometries.push(M.Sphere.unit())
+    p = model.primitives.push(M.Primitive(geometry=g))
+    m = model.meshes.push(M.Mesh(primitives=[p]))
+    n = model.nodes.push(M.Node(mesh=m, trs=M.Trs(translation=(0.0, 0.0, -1.0), scale=(1.0, 2.0, 1.0))))
+    model.root.children.append(n)
+    scene = M.Scene()
+    scene.push_model(model)
+    scene.push_model(M.create_default_model())
+    return scene
+
+
+def cube_scene():
+    model = M.Model()
+    ggx = model.materials.push(M.GgxMaterial(diffuse=(0.7, 0.3, 0.2, 1.0), specular=(0.2, 0.2, 0.2, 1.0), roughness=0.4))
+    phong = model.materials.push(M.PhongMaterial(diffuse=(0.2, 0.6, 0.3, 1.0)))
+    cube = model.geometries.push(M.TriangleMesh.cube())
+    quad = model.geometries.push(M.TriangleMesh.quad((2.0, 2.0)))
+    cube_prim = model.primitives.push(M.Primitive(geometry=cube, material=ggx))
+    quad_prim = model.primitives.push(M.Primitive(geometry=quad, material=phong))
+    cube_mesh = model.meshes.push(M.Mesh(primitives=[cube_prim]))
+    quad_mesh = model.meshes.push(M.Mesh(primitives=[quad_prim]))
+    cube_node = model.nodes.push(M.Node(mesh=cube_mesh, trs=M.Trs(rotation=M.quat_axis_angle((0.0, 1.0, 0.0), 0.6))))
+    group = model.nodes.push(M.Node(children=[cube_node], trs=M.Trs(translation=(0.25, 0.0, -0.5), scale=(1.2, 1.2, 1.2))))
+    floor = model.nodes.push(M.Node(mesh=quad_mesh, trs=M.Trs(translation=(0.0, -0.8, 0.0),
+                                                               rotation=M.quat_axis_angle((1.0, 0.0, 0.0), -1.5707964),
+                                                               scale=(6.0, 6.0, 6.0))))
+    model.root.children += [group, floor]
+    scene = M.Scene()
+    scene.push_model(model)
+    scene.push_model(M.create_default_model())
+    return scene
+
+
+SCENES = {"triangle": triangle_scene, "sphere": sphere_scene, "cube": cube_scene}
+
+
+def _raw(ctypes_array, count, ctype):
+    return bytes(C.string_at(ctypes_array, count * C.sizeof(ctype))) if count else b""
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_cpp_flatten_matches_python_flatten(host_mirror, tmp_path, name):
+    subprocess.run([host_mirror, "describe", name, str(tmp_path)], check=True)
+    d = flatten(SCENES[name]())
+    c = d.c
+
+    def blob(n):
+        return (tmp_path / f"{n}.bin").read_bytes()
+
+    assert blob("nodes") == _raw(c.nodes, c.node_count, abi.RaycaNode)
+    assert blob("meshes") == _raw(c.meshes, c.mesh_count, abi.RaycaMesh)
+    assert blob("primitives") == _raw(c.primitives, c.primitive_count, abi.RaycaPrimitive)
+    assert blob("materials") == _raw(c.materials, c.material_count, abi.RaycaMaterial)
+    assert blob("cameras") == _raw(c.cameras, c.camera_count, abi.RaycaCamera)
+    assert blob("lights") == _raw(c.lights, c.light_count, abi.RaycaLight)
+    assert blob("index_bytes") == d.index_bytes.tobytes()
+    n = d.positions.shape[0]
+    assert blob("positions") == d.positions.tobytes()
+    # a NULL attribute array means Vertex::default() (vertex.rs:164-175); the C++ side always spells it out
+    defaults = {"colors": (1, 1, 1, 1), "normals": (0, 0, 1), "tangents": (0, 0, 0), "bitangents": (0, 0, 0), "uvs": (0, 0)}
+    for attr, dv in defaults.items():
+        a = getattr(d, attr)
+        want = np.tile(np.array([dv], np.float32), (n, 1)) if a is None else a
+        assert blob(attr) == want.tobytes(), attr
+
+
+def test_quat_axis_angle_agrees():
+    # same f32 recipe on both sides (rayca-math/src/quat.rs:66-75): cube_scene above depends on it bit for bit
+    q = M.quat_axis_angle((0.0, 1.0, 0.0), 0.6)
+    assert abs(q[1] - math.sin(0.3)) < 1e-6 and abs(q[3] - math.cos(0.3)) < 1e-6
+
+
+def test_png_writer(host_mirror, tmp_path):
+    """Image::dump_png (rayca-model/src/image.rs:160-169): what the C++ mirror writes must decode (zlib stored
+    blocks, CRC, Adler) to the frame it was given.  Uses `describe`-free path: a 3x2 image via ctypes is not
+    available from the binary, so decode the PNG the GPU test writes when present; here only the encoder's
+    container maths is checked through a tiny pure-Python decode of a file produced by the same routine."""
+    import struct
+    import zlib
+    # produce a PNG with the header-only encoder through a two-line C++ program
+    src = tmp_path / "png.cpp"
+    src.write_text('#include "rayca.hpp"\nint main(int, char** a) { rayca::Image im(3, 2, rayca::ColorType::RGBA8);'
+                   ' for (size_t i = 0; i < im.data.size(); ++i) im.data[i] = (uint8_t)(i * 11); im.dump_png(a[1]); }\n')
+    exe = tmp_path / "png"
+    libdir = os.path.join(ROOT, "rayca_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + libdir,
+                    "-lrayca_hip", "-Wl,-rpath," + libdir], check=True)
+    out = tmp_path / "o.png"
+    subprocess.run([str(exe), str(out)], check=True)
+    b = out.read_bytes()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(b):
+        (ln,) = struct.unpack(">I", b[pos:pos + 4])
+        typ, body = b[pos + 4:pos + 8], b[pos + 8:pos + 8 + ln]
+        (crc,) = struct.unpack(">I", b[pos + 8 + ln:pos + 12 + ln])
+        assert crc == zlib.crc32(typ + body)
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + ln
+    assert ihdr == (3, 2, 8, 6, 0, 0, 0)
+    raw = zlib.decompress(idat)
+    rows = [raw[i * 13 + 1:(i + 1) * 13] for i in range(2)]
+    assert b"".join(rows) == bytes((i * 11) & 0xFF for i in range(24))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["triangle", "cube", "sphere"])
+def test_cpp_draw_matches_python_draw(gpu, host_mirror, tmp_path, name):
+    png = tmp_path / f"{name}.png"
+    subprocess.run([host_mirror, "draw", name, "frame", str(png)], check=True, cwd=tmp_path)
+    got = np.frombuffer((tmp_path / "frame.bin").read_bytes(), np.uint8).reshape(256, 256, 4)
+    cfg = Config(integrator=IntegratorStrategy.Flat) if name == "sphere" else Config()
+    image = M.Image(256, 256)
+    SoftRenderer(cfg).draw(SCENES[name](), image)
+    assert np.array_equal(got, image.data)
+    assert got[..., :3].any(), "frame is black"
+    assert png.stat().st_size > 256 * 256 * 4
