@@ -269,6 +269,15 @@ enum {
   RAYCA_TRAVERSAL_EXHAUSTIVE = 1
 };
 
+enum {
+  /* generation kernels where the Config allows them (Flat; Pathtracer with Nee/None direct and Cosine/
+   * Hemisphere indirect sampling, one indirect sample per vertex, no roulette), else the stack machine */
+  RAYCA_ENGINE_AUTO = 0,
+  /* always the per-pixel stack machine (k_general): every IntegratorStrategy / SamplerStrategy the
+   * reference has.  Same results as AUTO where both apply (tested); slower. */
+  RAYCA_ENGINE_GENERAL = 1
+};
+
 typedef struct RaycaBuildOptions {
   uint32_t builder;   /* RAYCA_BUILDER_* */
   uint32_t device;    /* HIP device ordinal */
@@ -290,7 +299,8 @@ typedef struct RaycaRenderOptions {
   uint32_t collect_stats; /* 1: run the instrumented kernel variant that counts boxes/triangles */
   RaycaTile tile;         /* all zero => whole frame */
   void* stream;           /* hipStream_t to launch on, NULL => the scene's own stream */
-  uint32_t reserved[4];
+  uint32_t engine;        /* RAYCA_ENGINE_*: which kernel family renders the frame */
+  uint32_t reserved[3];
 } RaycaRenderOptions;
 
 /* Filled by every render call (all counters are per call, summed over spp and generations). */

@@ -1358,6 +1358,7 @@ static int next_russian_roulette(Col next_throughput, Rng* rng, float* weight) {
 static int pathtracer_trace_impl(Ctx* cx, Ray ray, uint32_t depth, int collect_emissive, uint32_t key, Col* out) {
   const RaycaConfig* cfg = cx->cfg;
   if (!cfg->russian_roulette && depth >= cfg->max_depth) return 0;
+  if (depth > 0) cx->rays_bounce++; /* statistics: secondary rays that are actually traced */
   HitInfo hit;
   if (!tlas_intersects(cx, ray, &hit)) return 0;
   cx->hits_shaded++;
@@ -1382,7 +1383,6 @@ static int pathtracer_trace_impl(Ctx* cx, Ray ray, uint32_t depth, int collect_e
         else continue;
       }
       Col indirect_sample;
-      cx->rays_bounce++;
       if (pathtracer_trace_impl(cx, next_ray, depth + 1, child_collect, oracle_rng_child(key, k), &indirect_sample))
         li = cadd(li, indirect_get_radiance(cx, &hit, omega_i, indirect_sample, weight));
     }
@@ -1426,6 +1426,7 @@ static Col whitted_lights(Ctx* cx, HitInfo* hit, Col acc) {
 }
 static int raytracer_trace(Ctx* cx, Ray ray, uint32_t depth, Col* out) { /* raytracer.rs:16-76 */
   if (depth > cx->cfg->max_depth) return 0;
+  if (depth > 0) cx->rays_bounce++;
   HitInfo hit;
   if (!tlas_intersects(cx, ray, &hit)) return 0;
   cx->hits_shaded++;
@@ -1433,7 +1434,6 @@ static int raytracer_trace(Ctx* cx, Ray ray, uint32_t depth, Col* out) { /* rayt
   Col light_contribution = whitted_lights(cx, &hit, COL_BLACK);
   Ray reflection_ray = ray_new(hi_next_ray_origin(&hit), hi_reflection(&hit));
   Col reflection_color;
-  cx->rays_bounce++;
   if (raytracer_trace(cx, reflection_ray, depth + 1, &reflection_color))
     light_contribution = cadd(light_contribution, cmulf(cmul(reflection_color, hi_specular(&hit)), 1.0f));
   *out = cadd(ambient_emissive, light_contribution);
@@ -1441,6 +1441,7 @@ static int raytracer_trace(Ctx* cx, Ray ray, uint32_t depth, Col* out) { /* rayt
 }
 static int scratcher_trace(Ctx* cx, Ray ray, uint32_t depth, Col* out) { /* scratcher.rs:16-89 */
   if (depth > cx->cfg->max_depth) return 0;
+  if (depth > 0) cx->rays_bounce++;
   HitInfo hit;
   if (!tlas_intersects(cx, ray, &hit)) return 0;
   cx->hits_shaded++;
@@ -1448,7 +1449,6 @@ static int scratcher_trace(Ctx* cx, Ray ray, uint32_t depth, Col* out) { /* scra
   if (c_is_transparent(hi_color(&hit))) {
     V4 torigin = add4(hit.hit.point, vscale(vneg(hi_normal(&hit)), ORC_RAY_BIAS)); /* hit.rs:178-187 */
     Col transmit;
-    cx->rays_bounce++;
     if (scratcher_trace(cx, ray_new(torigin, hit.hit.ray.dir), depth + 1, &transmit)) {
       transmit = cover(transmit, hi_color(&hit));
       pixel_color = cadd(pixel_color, transmit);
@@ -1458,7 +1458,6 @@ static int scratcher_trace(Ctx* cx, Ray ray, uint32_t depth, Col* out) { /* scra
   V4 reflection = hi_reflection(&hit);
   Ray reflection_ray = ray_new(hi_next_ray_origin(&hit), reflection);
   Col refl;
-  cx->rays_bounce++;
   if (scratcher_trace(cx, reflection_ray, depth + 1, &refl)) {
     Irradiance ir = irradiance_new(refl, &hit, reflection);
     pixel_color = cadd(pixel_color, hi_get_radiance(cx, &hit, ir));

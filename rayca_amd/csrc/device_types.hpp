@@ -41,6 +41,8 @@ struct DevLight {
   float position[4];  // Point3::from(trs.get_translation()) of the node-LOCAL trs (nee.rs:133-134)
   float normal[4];    // quad: normalized(ab x ac)  (light/quad.rs:36-38)
   float area, pad1, pad2, pad3;
+  float direction[4];  // directional: -(rotation * X)  (light/directional.rs:47-51)
+  float trs_translation[4], trs_rotation[4], trs_scale[4];  // node-LOCAL Trs (QuadLight::intersects, quad.rs:138-159)
 };
 
 struct DevScene {
@@ -88,6 +90,7 @@ struct TraceLaunch {
 
 struct TraceCounters {
   unsigned long long boxes, tris, shaded, shadow, bounce, box_slots, tri_slots;
+  unsigned long long flags;  // k_general: kFlagUnsupported | kFlagTooDeep
 };
 
 // ray queue entry between two generations (32 B)

@@ -642,7 +642,7 @@ __device__ __forceinline__ void push_ray(bool has, const QueuedRay& qr, QueuedRa
   if (has) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = qr;
 }
 
-constexpr int kModeFlat = 0, kModePath = 1;
+constexpr int kModeFlat = 0, kModePath = 1, kModeGeneral = 2;
 
 // One NEE sample (sampler/nee.rs:72-166), split around its shadow ray: everything that does not depend
 // on the shadow ray's outcome is evaluated first (pure functions, same values), so that only the
@@ -976,6 +976,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float*
     }
   }
 }
+
+#include "general.inc"
 
 }  // namespace
 }  // namespace rayca

@@ -135,8 +135,9 @@ int main(int argc, char** argv) {
     }
     // the reference's `triangle` test verbatim from here: 256x256 RGBA8, default renderer
     Image image(256, 256, ColorType::RGBA8);
+    // rayca-soft/tests/gltf.rs:12-18: the sphere test runs the Scratcher without a BVH
     SoftRenderer renderer = name == "sphere"
-                                ? SoftRenderer::new_with_config(Config::builder().integrator(IntegratorStrategy::Flat).build())
+                                ? SoftRenderer::new_with_config(Config::builder().bvh(false).integrator(IntegratorStrategy::Scratcher).build())
                                 : SoftRenderer();
     renderer.draw(scene, image);
     dump(".", out.c_str(), image.data);  // writes ./<out>.bin

@@ -158,7 +158,7 @@ def test_cpp_draw_matches_python_draw(gpu, host_mirror, tmp_path, name):
     png = tmp_path / f"{name}.png"
     subprocess.run([host_mirror, "draw", name, "frame", str(png)], check=True, cwd=tmp_path)
     got = np.frombuffer((tmp_path / "frame.bin").read_bytes(), np.uint8).reshape(256, 256, 4)
-    cfg = Config(integrator=IntegratorStrategy.Flat) if name == "sphere" else Config()
+    cfg = Config(bvh=False, integrator=IntegratorStrategy.Scratcher) if name == "sphere" else Config()
     image = M.Image(256, 256)
     SoftRenderer(cfg).draw(SCENES[name](), image)
     assert np.array_equal(got, image.data)

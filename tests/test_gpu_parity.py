@@ -281,11 +281,13 @@ def test_errors_mirror_the_reference_panics(gpu):
         ds.render(Config(), 8, 8)
     assert e.value.code == abi.ERR_EMPTY_SCENE          # Tlas::intersects assert  tlas.rs:272
     ds = DeviceScene(flatten(scenes.box_scene()), Config())
-    for bad in (Config(integrator=IntegratorStrategy.Raytracer), Config(russian_roulette=True),
-                Config(direct_sampler=SamplerStrategy.Mis), Config(light_samples=2)):
+    for bad in (Config(direct_sampler=SamplerStrategy.Mis), Config(indirect_sampler=SamplerStrategy.Nee, direct_sampler=SamplerStrategy.NONE)):
         with pytest.raises(RaycaError) as e:
             ds.render(bad, 8, 8)
-        assert e.value.code == abi.ERR_UNSUPPORTED       # fails loudly, never falls back to a CPU path
+        assert e.value.code == abi.ERR_UNSUPPORTED       # todo!()/panic arms of the reference: fails loudly, no CPU fallback
+    with pytest.raises(RaycaError) as e:
+        ds.render(Config(integrator=17), 8, 8)
+    assert e.value.code == abi.ERR_BAD_ARG
     with pytest.raises(RaycaError) as e:
         ds.render(Config(), 0, 8)
     assert e.value.code == abi.ERR_BAD_ARG
