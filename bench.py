@@ -93,7 +93,7 @@ def main():
     if world > 1:
         dist.barrier()
     from rayca_amd import DeviceScene, abi, flatten, scenes
-    from rayca_amd.distributed import gather_frame, rows_of, tile_of
+    from rayca_amd.distributed import FrameGatherer, rows_of, tile_of
 
     wl = workload_config(args.workload)
     cfg, W, H = wl["cfg"], wl["width"], wl["height"]
@@ -114,6 +114,9 @@ def main():
     for e in ev_gather:
         e.record(comm)
     counter = [0]
+    gather_dev = dev if backend == "nccl" else torch.device("cpu")
+    gatherer = FrameGatherer(H, W, args.band_rows, gather_dev) if world > 1 else None
+    frames = [torch.empty((H, W, 4), dtype=torch.uint8, device=gather_dev) for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
 
     def step(want_stats=False):
         i = counter[0] & 1
@@ -128,10 +131,10 @@ def main():
         with torch.cuda.stream(comm):
             comm.wait_event(ev_render[i])
             if backend == "nccl":
-                frame = gather_frame(buf, H, args.band_rows)
+                frame = gatherer(buf, frames[i])
             else:  # rehearsal: gloo gathers host tensors
                 comm.synchronize()
-                frame = gather_frame(buf.cpu(), H, args.band_rows)
+                frame = gatherer(buf.cpu(), frames[i])
             ev_gather[i].record(comm)
         return st, frame
 

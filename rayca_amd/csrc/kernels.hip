@@ -22,6 +22,9 @@ namespace rayca {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef RAYCA_TRACE_MIN_WAVES
+#define RAYCA_TRACE_MIN_WAVES 1
+#endif
 #ifndef RAYCA_MIN_WAVES_FLAT
 #define RAYCA_MIN_WAVES_FLAT 5
 #endif
@@ -948,7 +951,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers 
 }
 
 template <bool ORDERED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
+__global__ __launch_bounds__(kBlock, RAYCA_TRACE_MIN_WAVES) void k_trace_rays(DevScene sc, const float* rays, uint32_t count, float* t_out, uint32_t* prim_out, float* uv_out,
                                                        TraceCounters* counters, TraceLaunch tl) {
   extern __shared__ uint32_t lds_stack[];
   NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);

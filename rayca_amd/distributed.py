@@ -26,27 +26,50 @@ def rows_of(tile, height: int) -> torch.Tensor:
     return y[((y // max(band, 1)) % parts) == part]
 
 
+class FrameGatherer:
+    """Everything about the frame-end gather that does not change from frame to frame, set up once: per-rank row
+    counts, the receive buffer on `dst`, and ONE permutation that de-interleaves the gathered bands into frame
+    order.  Per frame that leaves one collective and one index_select launch on the caller's stream."""
+
+    def __init__(self, height: int, width: int, band_rows: int, device, dst: int = 0, group=None):
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.height, self.width = height, width
+        rows = [rows_of(tile_of(r, self.world, band_rows), height) for r in range(self.world)]
+        self.counts = [int(r.numel()) for r in rows]
+        self.max_rows = max(self.counts)
+        self.my_rows = self.counts[self.rank]
+        self.pad = None
+        if self.my_rows != self.max_rows:  # ragged heights: every rank contributes the same count
+            self.pad = torch.zeros((self.max_rows, width, 4), dtype=torch.uint8, device=device)
+        self.recv = self.views = self.perm = None
+        if self.rank == dst and self.world > 1:
+            self.recv = torch.empty((self.world, self.max_rows, width, 4), dtype=torch.uint8, device=device)
+            self.views = [self.recv[r] for r in range(self.world)]
+            # frame row y lives at gathered row perm[y] = rank * max_rows + position within that rank's rows
+            perm = torch.empty(height, dtype=torch.int64)
+            for r, ys in enumerate(rows):
+                perm[ys] = r * self.max_rows + torch.arange(ys.numel())
+            self.perm = perm.to(device)
+
+    def __call__(self, local_rows: torch.Tensor, out: torch.Tensor = None):
+        """local_rows: (rows_of_this_rank, W, 4) uint8.  Returns the (height, W, 4) frame on `dst`, None elsewhere."""
+        if self.world == 1:
+            return local_rows
+        send = local_rows
+        if self.pad is not None:
+            self.pad[: self.my_rows].copy_(local_rows)
+            send = self.pad
+        dist.gather(send, self.views, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        if out is None:
+            out = torch.empty((self.height, self.width, 4), dtype=torch.uint8, device=self.recv.device)
+        torch.index_select(self.recv.view(self.world * self.max_rows, self.width, 4), 0, self.perm, out=out)
+        return out
+
+
 def gather_frame(local_rows: torch.Tensor, height: int, band_rows: int, dst: int = 0, group=None):
-    """local_rows: (rows_of_this_rank, W, 4) uint8 on this rank's device.  Returns the assembled
-    (height, W, 4) frame on rank `dst`, None elsewhere.  One collective per frame."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
-        return local_rows
-    width = local_rows.shape[1]
-    counts = [int(rows_of(tile_of(r, world, band_rows), height).numel()) for r in range(world)]
-    max_rows = max(counts)
-    send = local_rows
-    if send.shape[0] != max_rows:  # ragged heights: pad so every rank contributes the same count
-        pad = torch.zeros((max_rows - send.shape[0], width, 4), dtype=send.dtype, device=send.device)
-        send = torch.cat([send, pad], 0)
-    send = send.contiguous()
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    frame = torch.empty((height, width, 4), dtype=send.dtype, device=send.device)
-    for r in range(world):
-        idx = rows_of(tile_of(r, world, band_rows), height).to(send.device)
-        frame.index_copy_(0, idx, recv[r][: counts[r]])
-    return frame
+    """One-off form of FrameGatherer (tests, single frames)."""
+    return FrameGatherer(height, local_rows.shape[1], band_rows, local_rows.device, dst, group)(local_rows.contiguous())
