@@ -270,12 +270,19 @@ enum {
 };
 
 enum {
-  /* generation kernels where the Config allows them (Flat; Pathtracer with Nee/None direct and Cosine/
-   * Hemisphere indirect sampling, one indirect sample per vertex, no roulette), else the stack machine */
+  /* generation-by-generation rendering where the Config allows it (Flat; Pathtracer with Nee/None direct
+   * and Cosine/Hemisphere indirect sampling, one indirect sample per vertex, no roulette) -- with whichever
+   * of FUSED / WAVEFRONT measured faster -- else the stack machine */
   RAYCA_ENGINE_AUTO = 0,
   /* always the per-pixel stack machine (k_general): every IntegratorStrategy / SamplerStrategy the
    * reference has.  Same results as AUTO where both apply (tested); slower. */
-  RAYCA_ENGINE_GENERAL = 1
+  RAYCA_ENGINE_GENERAL = 1,
+  /* the generation kernels' frames with traversal split from shading: lean trace kernels with lane-level
+   * refill + a streaming shade kernel per generation (wavefront.inc).  Same Configs as the generation
+   * kernels, same bits (tested). */
+  RAYCA_ENGINE_WAVEFRONT = 2,
+  /* the fused persistent kernel per generation (k_generation) */
+  RAYCA_ENGINE_FUSED = 3
 };
 
 typedef struct RaycaBuildOptions {

@@ -34,9 +34,9 @@ GEOMETRY_TRIANGLE_MESH, GEOMETRY_SPHERE = 0, 1
 INDEX_U8, INDEX_U16, INDEX_U32 = 5121, 5123, 5125
 COLOR_RGB8, COLOR_RGBA8, COLOR_RGBA32F = 0, 1, 2
 BUILDER_REFERENCE, BUILDER_SAH = 0, 1
-ENGINE_AUTO, ENGINE_GENERAL = 0, 1
+ENGINE_AUTO, ENGINE_GENERAL, ENGINE_WAVEFRONT, ENGINE_FUSED = 0, 1, 2, 3
 TRAVERSAL_ORDERED, TRAVERSAL_EXHAUSTIVE = 0, 1
-ENGINE_AUTO, ENGINE_GENERAL = 0, 1
+ENGINE_AUTO, ENGINE_GENERAL, ENGINE_WAVEFRONT, ENGINE_FUSED = 0, 1, 2, 3
 
 
 class RaycaConfig(C.Structure):

@@ -981,6 +981,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_TRACE_MIN_WAVES) void k_trace_rays(De
 }
 
 #include "general.inc"
+#include "wavefront.inc"
 
 }  // namespace
 }  // namespace rayca
