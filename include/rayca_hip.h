@@ -328,7 +328,9 @@ typedef struct RaycaStats {
   uint32_t kernel_launches;
   uint32_t trace_kernel_launches;
   uint32_t rows_rendered;
-  uint32_t reserved;
+  /* node format of this frame's launches: bit 0 = generation 0 used 4-wide nodes, bit 1 = the bounce
+   * generations did, bit 8 = this was a calibration frame (the scene is still timing both formats) */
+  uint32_t node_format;
 } RaycaStats;
 
 typedef struct RaycaSceneInfo {

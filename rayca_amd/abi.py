@@ -209,11 +209,11 @@ class RaycaStats(C.Structure):
         ("kernel_launches", C.c_uint32),
         ("trace_kernel_launches", C.c_uint32),
         ("rows_rendered", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("node_format", C.c_uint32),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class RaycaSceneInfo(C.Structure):
