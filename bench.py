@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--builder", default="sah", choices=["sah", "reference"],
                     help="sah: SAH tree with empty-seeded candidate boxes (default); reference: the reference's tree, quirks included")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="frames rendered concurrently (frame contexts + streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -104,28 +105,32 @@ def main():
     info = ds.info()
     tile = tile_of(rank, world, args.band_rows)
     my_rows = int(rows_of(tile, H).numel())
-    # two output buffers: the gather of frame i (comm stream) overlaps the render of frame i+1
-    outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    # F frames in flight: frame i renders with frame context i % F on its own stream into its own buffer, so the tail
+    # of one frame (a few slow waves) overlaps the head of the next; with N > 1 the gather of a finished frame runs on
+    # the comm stream meanwhile.  Every frame is still one complete pass: camera rays -> pixels (-> gather).
+    F = max(1, min(args.frames_in_flight, 4))
+    outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
     out = outs[0]
-    stream = torch.cuda.Stream(dev)       # render kernels
-    comm = torch.cuda.Stream(dev)         # frame gather (RCCL)
-    ev_render = [torch.cuda.Event() for _ in range(2)]
-    ev_gather = [torch.cuda.Event() for _ in range(2)]
+    streams = [torch.cuda.Stream(dev) for _ in range(F)]   # render kernels, one stream per frame in flight
+    stream = streams[0]
+    comm = torch.cuda.Stream(dev)                           # frame gather (RCCL)
+    ev_render = [torch.cuda.Event() for _ in range(F)]
+    ev_gather = [torch.cuda.Event() for _ in range(F)]
     for e in ev_gather:
         e.record(comm)
     counter = [0]
     gather_dev = dev if backend == "nccl" else torch.device("cpu")
     gatherer = FrameGatherer(H, W, args.band_rows, gather_dev) if world > 1 else None
-    frames = [torch.empty((H, W, 4), dtype=torch.uint8, device=gather_dev) for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    frames = [torch.empty((H, W, 4), dtype=torch.uint8, device=gather_dev) for _ in range(F)] if (world > 1 and rank == 0) else [None] * F
 
     def step(want_stats=False):
-        i = counter[0] & 1
+        i = counter[0] % F
         counter[0] += 1
-        buf = outs[i]
-        with torch.cuda.stream(stream):
-            stream.wait_event(ev_gather[i])   # the previous gather out of this buffer has finished
-            st = ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=want_stats)
-            ev_render[i].record(stream)
+        buf, st_i = outs[i], streams[i]
+        with torch.cuda.stream(st_i):
+            st_i.wait_event(ev_gather[i])   # the previous gather out of this buffer has finished
+            st = ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_i.cuda_stream, want_stats=want_stats, context=i)
+            ev_render[i].record(st_i)
         if world == 1:
             return st, buf
         with torch.cuda.stream(comm):
@@ -146,6 +151,9 @@ def main():
         node_format = st0["node_format"]
         if not node_format & 256:
             break
+    for i in range(1, F):   # first use of a frame context allocates its work buffers: not inside the timed region
+        ds.render_device(cfg, W, H, outs[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i)
+    torch.cuda.synchronize()
     # instrumented run with the node format just chosen: rays + algorithmic bytes of this rank's launch (not timed)
     counted = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True, collect_stats=True)
     rays_rank = counted["rays_primary"] + counted["rays_shadow"] + counted["rays_bounce"]
@@ -207,7 +215,7 @@ def main():
                    "node_format": {"generation0": "4-wide" if node_format & 1 else "binary", "bounces": "4-wide" if node_format & 2 else "binary", "chosen_by": "timing both on this scene"},
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
-                   "rays_per_frame": int(rays_total), "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
+                   "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
                    "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "none")},
         "roofline": {"bound": "hbm", "kernel": "k_generation (generation 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

@@ -307,7 +307,11 @@ typedef struct RaycaRenderOptions {
   RaycaTile tile;         /* all zero => whole frame */
   void* stream;           /* hipStream_t to launch on, NULL => the scene's own stream */
   uint32_t engine;        /* RAYCA_ENGINE_*: which kernel family renders the frame */
-  uint32_t reserved[3];
+  /* Frame context 0..3.  Each context owns its work buffers and its default stream, so frames rendered with
+   * different contexts (and different streams) may be in flight at the same time; calls that use the same
+   * context are serialised.  The scene (BVH, triangles, materials) is shared. */
+  uint32_t context;
+  uint32_t reserved[2];
 } RaycaRenderOptions;
 
 /* Filled by every render call (all counters are per call, summed over spp and generations). */

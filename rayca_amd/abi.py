@@ -190,7 +190,8 @@ class RaycaRenderOptions(C.Structure):
         ("tile", RaycaTile),
         ("stream", C.c_void_p),
         ("engine", C.c_uint32),
-        ("reserved", C.c_uint32 * 3),
+        ("context", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
     ]
 
 

@@ -26,6 +26,13 @@ def load():
             raise RaycaError(abi.ERR_NO_DEVICE,
                              f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
                              " (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; the system ROCm this library links has the
+        # same SONAMEs.  Whichever is loaded first serves both, and torch only finds the GPU with its own pair, so
+        # when torch is installed it goes first (bench.py and the multi-GPU path use torch for streams and RCCL).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = abi.bind_product_signatures(C.CDLL(LIB_PATH))
     return _lib
 

@@ -1,0 +1,32 @@
+"""Frames in flight: one scene handle per stream, frames dealt round-robin.  Does the tail of frame i overlap the
+head of frame i+1?  usage: python tests/gpu_inflight_probe.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from rayca_amd import Config, DeviceScene, flatten, scenes, abi
+W, H = 1920, 1080
+cfg = Config(max_depth=1)
+desc = flatten(scenes.atrium_scene())
+dev = torch.device("cuda", 0)
+NH = 3
+hs = [DeviceScene(desc, cfg, builder=abi.BUILDER_SAH) for _ in range(NH)]
+streams = [torch.cuda.Stream(dev) for _ in range(NH)]
+for parts in (1, 8):
+    tile = (0, parts, 8)
+    rows = hs[0].tile_rows(tile, H)
+    outs = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(NH)]
+    for h, s, o in zip(hs, streams, outs):
+        for _ in range(8):
+            h.render_device(cfg, W, H, o.data_ptr(), 0, tile=tile, stream=s.cuda_stream, want_stats=True)
+    torch.cuda.synchronize()
+    for inflight in (1, 2, 3):
+        K = 300
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            j = i % inflight
+            hs[j].render_device(cfg, W, H, outs[j].data_ptr(), 0, tile=tile, stream=streams[j].cuda_stream)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / K * 1e3
+        print(f"parts {parts} frames in flight {inflight}: {t:.4f} ms/frame", flush=True)

@@ -66,3 +66,24 @@ def test_engines_agree_at_full_size(gpu):
         (u8a, fa, sa), (u8b, fb, sb) = both(ds, cfg, w, h, want_f32=True)
         assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), f"max abs diff {np.abs(fa - fb).max():.3e}"
         assert sa["rays_shadow"] == sb["rays_shadow"] and sa["rays_bounce"] == sb["rays_bounce"]
+
+
+def test_frames_in_flight_on_separate_contexts(gpu):
+    """Three frames of one scene in flight on three streams (RaycaRenderOptions.context): each must equal the frame
+    rendered alone.  Different configs per context, so a shared work buffer would show."""
+    import torch
+    ds, _ = G.pair("cornell")
+    dev = torch.device("cuda", 0)
+    cfgs = [Config(max_depth=3, seed=1), Config(max_depth=1), Config(integrator=I.Flat)]
+    w, h = 640, 360
+    alone = [ds.render(c, w, h, want_f32=False)[0] for c in cfgs]
+    streams = [torch.cuda.Stream(dev) for _ in cfgs]
+    outs = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in cfgs]
+    for _ in range(5):
+        for i, c in enumerate(cfgs):
+            ds.render_device(c, w, h, outs[i].data_ptr(), 0, stream=streams[i].cuda_stream, context=i)
+    torch.cuda.synchronize()
+    for i in range(len(cfgs)):
+        assert np.array_equal(outs[i].cpu().numpy(), alone[i]), i
+    with pytest.raises(Exception):
+        ds.render(cfgs[0], 8, 8, context=9)
