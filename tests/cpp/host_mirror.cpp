@@ -3,6 +3,8 @@
 //
 //   host_mirror describe <scene> <out_dir>     flatten only, dump every array of the RaycaSceneDesc (no GPU)
 //   host_mirror draw <scene> <out.rgba> [png]  SoftRenderer::draw on device 0, raw RGBA8 (+ PNG)
+//   host_mirror png <in.png> <out_dir>         decode a PNG with the loader's decoder, dump w/h/type + texels
+// scene "gltf:<path>" = rayca-soft/tests/gltf.rs:191-204 `gltf::cube`: the file + create_default_model()
 //
 // tests/test_cpp_host.py compares `describe` with rayca_amd.flatten of the same scene built through the
 // Python mirror, and `draw` with the Python host's frame.
@@ -12,6 +14,7 @@
 #include <string>
 
 #include "rayca.hpp"
+#include "rayca_gltf.hpp"
 
 using namespace rayca;
 
@@ -91,7 +94,16 @@ static Scene cube_scene() {
   return scene;
 }
 
+// rayca-soft/tests/gltf.rs:191-204
+static Scene gltf_scene(const std::string& path) {
+  Scene scene;
+  push_gltf_from_path(scene, path);
+  scene.push_model(SoftRenderer::create_default_model());
+  return scene;
+}
+
 static Scene make(const std::string& name) {
+  if (name.rfind("gltf:", 0) == 0) return gltf_scene(name.substr(5));
   if (name == "triangle") return triangle_scene();
   if (name == "sphere") return sphere_scene();
   if (name == "cube") return cube_scene();
@@ -115,6 +127,13 @@ int main(int argc, char** argv) {
   }
   const std::string mode = argv[1], name = argv[2], out = argv[3];
   try {
+    if (mode == "png") {
+      const Image im = gltf_detail::decode_png(gltf_detail::read_file(name));
+      const std::vector<uint32_t> head = {im.w, im.h, (uint32_t)im.color_type};
+      dump(out, "png_head", head);
+      dump(out, "png_texels", im.data);
+      return 0;
+    }
     const Scene scene = make(name);
     if (mode == "describe") {
       const FlatScene flat(scene);
@@ -129,6 +148,9 @@ int main(int argc, char** argv) {
       dump(out, "uvs", flat.uvs);
       dump(out, "index_bytes", flat.index_bytes);
       dump(out, "materials", flat.materials);
+      dump(out, "textures", flat.textures);
+      dump(out, "images", flat.images);
+      dump(out, "image_bytes", flat.image_bytes);
       dump(out, "cameras", flat.cameras);
       dump(out, "lights", flat.lights);
       return 0;
