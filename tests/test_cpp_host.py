@@ -164,3 +164,170 @@ def test_cpp_draw_matches_python_draw(gpu, host_mirror, tmp_path, name):
     assert np.array_equal(got, image.data)
     assert got[..., :3].any(), "frame is black"
     assert png.stat().st_size > 256 * 256 * 4
+
+
+# ---- glTF ingestion in C++ (include/rayca_gltf.hpp; reference: rayca-model/src/loader/gltf.rs) -----------------------
+def test_cpp_gltf_loader_matches_python_loader_on_the_box(host_mirror, tmp_path):
+    """rayca-soft/tests/gltf.rs:191-204 `gltf::cube`: the Khronos Box (matrix node, u16 indices, data-URI buffer)."""
+    from rayca_amd import scenes
+    path = os.path.join(ROOT, "tests", "golden", "box.gltf")
+    subprocess.run([host_mirror, "describe", "gltf:" + path, str(tmp_path)], check=True)
+    d = flatten(scenes.box_scene())
+    c = d.c
+
+    def blob(n):
+        return (tmp_path / f"{n}.bin").read_bytes()
+
+    assert blob("nodes") == _raw(c.nodes, c.node_count, abi.RaycaNode)          # incl. the decomposed matrix node
+    assert blob("primitives") == _raw(c.primitives, c.primitive_count, abi.RaycaPrimitive)
+    assert blob("materials") == _raw(c.materials, c.material_count, abi.RaycaMaterial)
+    assert blob("cameras") == _raw(c.cameras, c.camera_count, abi.RaycaCamera)
+    assert blob("lights") == _raw(c.lights, c.light_count, abi.RaycaLight)
+    assert blob("index_bytes") == d.index_bytes.tobytes()
+    assert blob("positions") == d.positions.tobytes()
+    assert blob("normals") == d.normals.tobytes()
+
+
+def _png(width, height, color_type, texels, palette=None, trns=None):
+    """A PNG with every filter type in use and real (dynamic Huffman) deflate: what the C++ decoder must undo."""
+    import struct
+    import zlib
+    channels = {0: 1, 2: 3, 3: 1, 6: 4}[color_type]
+    rows = np.asarray(texels, np.uint8).reshape(height, width * channels).astype(np.int32)
+    bpp = channels
+    out = bytearray()
+    for y in range(height):
+        ft = y % 5
+        cur, up = rows[y], rows[y - 1] if y else np.zeros_like(rows[0])
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]])
+        if ft == 0: pred = 0
+        elif ft == 1: pred = a
+        elif ft == 2: pred = up
+        elif ft == 3: pred = (a + up) // 2
+        else:
+            p = a + up - c
+            pa, pb, pc = abs(p - a), abs(p - up), abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, up, c))
+        out.append(ft)
+        out += bytes(((cur - pred) & 0xFF).astype(np.uint8))
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, color_type, 0, 0, 0))
+    if palette is not None:
+        png += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        png += chunk(b"tRNS", bytes(trns))
+    comp = zlib.compress(bytes(out), 9)
+    half = len(comp) // 2
+    png += chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
+    return png
+
+
+@pytest.mark.parametrize("kind", ["rgba", "rgb", "grey", "palette"])
+def test_cpp_png_decoder(host_mirror, tmp_path, kind):
+    rng = np.random.default_rng(7)
+    w, h = 37, 23
+    smooth = (np.add.outer(np.arange(h) * 5, np.arange(w) * 3) % 256).astype(np.uint8)   # compressible + noise: dynamic Huffman
+    if kind == "rgba":
+        tex = np.stack([smooth, smooth[::-1], rng.integers(0, 256, (h, w), dtype=np.uint8), 255 - smooth], -1)
+        data, want, ct = _png(w, h, 6, tex), tex, abi.COLOR_RGBA8
+    elif kind == "rgb":
+        tex = np.stack([smooth, rng.integers(0, 4, (h, w), dtype=np.uint8) * 60, smooth.T[:h, :w] if smooth.T.shape == (h, w) else smooth], -1)
+        data, want, ct = _png(w, h, 2, tex), tex, abi.COLOR_RGB8
+    elif kind == "grey":
+        data, want, ct = _png(w, h, 0, smooth), np.repeat(smooth[..., None], 3, -1), abi.COLOR_RGB8
+    else:
+        pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+        alpha = rng.integers(0, 256, 10, dtype=np.uint8)
+        idx = (smooth % 16).astype(np.uint8)
+        a = np.where(idx < 10, alpha[np.minimum(idx, 9)], 255).astype(np.uint8)
+        data, want, ct = _png(w, h, 3, idx, pal.reshape(-1), alpha), np.concatenate([pal[idx], a[..., None]], -1), abi.COLOR_RGBA8
+    src = tmp_path / "in.png"
+    src.write_bytes(data)
+    subprocess.run([host_mirror, "png", str(src), str(tmp_path)], check=True)
+    head = np.frombuffer((tmp_path / "png_head.bin").read_bytes(), np.uint32)
+    assert tuple(head) == (w, h, ct)
+    got = np.frombuffer((tmp_path / "png_texels.bin").read_bytes(), np.uint8).reshape(h, w, -1)
+    assert np.array_equal(got, want)
+
+
+def _textured_gltf(tmp_path):
+    """Interleaved (strided) vertex buffer in an external .bin, u16 indices, TANGENT, a PNG data-URI texture."""
+    import base64
+    import json
+    pos = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (4, 1))
+    uv = np.array([[0, 1], [1, 1], [1, 0], [0, 0]], np.float32)
+    tan = np.array([[1, 0, 0, 1], [1, 0, 0, -1], [0.6, 0.8, 0, 1], [1, 0, 0, 1]], np.float32)
+    inter = np.concatenate([pos, nrm, uv, tan], 1)                     # 12 floats = 48-byte stride
+    idx = np.array([0, 1, 2, 2, 3, 0], np.uint16)
+    blob = inter.tobytes() + idx.tobytes()
+    (tmp_path / "quad.bin").write_bytes(blob)
+    tex = np.array([[[255, 0, 0, 255], [0, 255, 0, 255]], [[0, 0, 255, 255], [255, 255, 0, 128]]], np.uint8)
+    uri = "data:image/png;base64," + base64.b64encode(_png(2, 2, 6, tex)).decode()
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+        "nodes": [{"mesh": 0, "translation": [0.25, 0.0, -0.5], "rotation": [0.0, 0.0, 0.38268343, 0.92387953], "scale": [1.5, 1.5, 1.0], "name": "quad"}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2, "TANGENT": 3}, "indices": 4, "material": 0}]}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.8, 0.7, 1.0], "baseColorTexture": {"index": 0}, "metallicFactor": 0.25, "roughnessFactor": 0.5},
+                       "normalTexture": {"index": 0}}],
+        "textures": [{"source": 0}], "images": [{"uri": uri}],
+        "buffers": [{"uri": "quad.bin", "byteLength": len(blob)}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": inter.nbytes, "byteStride": 48},
+                        {"buffer": 0, "byteOffset": inter.nbytes, "byteLength": idx.nbytes}],
+        "accessors": [{"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": 4, "type": "VEC3"},
+                      {"bufferView": 0, "byteOffset": 24, "componentType": 5126, "count": 4, "type": "VEC2"},
+                      {"bufferView": 0, "byteOffset": 32, "componentType": 5126, "count": 4, "type": "VEC4"},
+                      {"bufferView": 1, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+    }
+    path = tmp_path / "quad.gltf"
+    path.write_text(json.dumps(doc))
+    return path, dict(pos=pos, nrm=nrm, uv=uv, tan=tan, idx=idx, tex=tex)
+
+
+def test_cpp_gltf_loader_strided_buffers_tangents_and_png_texture(host_mirror, tmp_path):
+    path, want = _textured_gltf(tmp_path)
+    out = tmp_path / "out"
+    out.mkdir()
+    subprocess.run([host_mirror, "describe", "gltf:" + str(path), str(out)], check=True)
+
+    def arr(n, dt):
+        return np.frombuffer((out / f"{n}.bin").read_bytes(), dt)
+
+    assert np.array_equal(arr("positions", np.float32).reshape(-1, 3), want["pos"])
+    assert np.array_equal(arr("normals", np.float32).reshape(-1, 3), want["nrm"])
+    assert np.array_equal(arr("uvs", np.float32).reshape(-1, 2), want["uv"])
+    assert np.array_equal(arr("tangents", np.float32).reshape(-1, 3), want["tan"][:, :3])
+    n, t, w = want["nrm"], want["tan"][:, :3], want["tan"][:, 3:4]
+    bit = np.stack([n[:, 1] * t[:, 2] - n[:, 2] * t[:, 1], n[:, 2] * t[:, 0] - n[:, 0] * t[:, 2], n[:, 0] * t[:, 1] - n[:, 1] * t[:, 0]], 1) * w
+    assert np.array_equal(arr("bitangents", np.float32).reshape(-1, 3), bit.astype(np.float32))   # gltf.rs:231-232
+    assert arr("index_bytes", np.uint8).tobytes() == want["idx"].tobytes()
+    prim = abi.RaycaPrimitive.from_buffer_copy((out / "primitives.bin").read_bytes())
+    assert (prim.index_type, prim.index_count, prim.vertex_count, prim.material) == (abi.INDEX_U16, 6, 4, 0)
+    mat = abi.RaycaMaterial.from_buffer_copy((out / "materials.bin").read_bytes())
+    assert (mat.kind, mat.albedo_texture, mat.normal_texture, mat.metallic_roughness_texture) == (abi.MATERIAL_PBR, 0, 0, abi.NONE)
+    assert np.allclose(list(mat.color), [0.9, 0.8, 0.7, 1.0]) and abs(mat.metallic_factor - 0.25) < 1e-7 and abs(mat.roughness_factor - 0.5) < 1e-7
+    img = abi.RaycaImage.from_buffer_copy((out / "images.bin").read_bytes())
+    assert (img.width, img.height, img.color_type) == (2, 2, abi.COLOR_RGBA8)
+    assert arr("image_bytes", np.uint8).tobytes() == want["tex"].tobytes()
+    nodes = (out / "nodes.bin").read_bytes()
+    last = abi.RaycaNode.from_buffer_copy(nodes[-C.sizeof(abi.RaycaNode):])      # the glTF node (TRS authored)
+    assert np.allclose(list(last.trs.translation), [0.25, 0.0, -0.5]) and np.allclose(list(last.trs.scale), [1.5, 1.5, 1.0])
+    assert np.allclose(list(last.trs.rotation), [0.0, 0.0, 0.38268343, 0.92387953]) and last.mesh == 0
+
+
+@pytest.mark.gpu
+def test_cpp_gltf_draw_matches_python(gpu, host_mirror, tmp_path):
+    """`gltf::cube` end to end in C++ (load, flatten, build, draw, PNG) against the Python host."""
+    from rayca_amd import scenes
+    path = os.path.join(ROOT, "tests", "golden", "box.gltf")
+    subprocess.run([host_mirror, "draw", "gltf:" + path, "frame", str(tmp_path / "cube.png")], check=True, cwd=tmp_path)
+    got = np.frombuffer((tmp_path / "frame.bin").read_bytes(), np.uint8).reshape(256, 256, 4)
+    image = M.Image(256, 256)
+    SoftRenderer(Config()).draw(scenes.box_scene(), image)
+    assert np.array_equal(got, image.data)
+    assert got[..., :3].any()
