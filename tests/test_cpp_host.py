@@ -315,7 +315,8 @@ def test_cpp_gltf_loader_strided_buffers_tangents_and_png_texture(host_mirror, t
     assert (img.width, img.height, img.color_type) == (2, 2, abi.COLOR_RGBA8)
     assert arr("image_bytes", np.uint8).tobytes() == want["tex"].tobytes()
     nodes = (out / "nodes.bin").read_bytes()
-    last = abi.RaycaNode.from_buffer_copy(nodes[-C.sizeof(abi.RaycaNode):])      # the glTF node (TRS authored)
+    sz = C.sizeof(abi.RaycaNode)
+    last = abi.RaycaNode.from_buffer_copy(nodes[3 * sz:4 * sz])   # scene root, scene node, model root, then the glTF node
     assert np.allclose(list(last.trs.translation), [0.25, 0.0, -0.5]) and np.allclose(list(last.trs.scale), [1.5, 1.5, 1.0])
     assert np.allclose(list(last.trs.rotation), [0.0, 0.0, 0.38268343, 0.92387953]) and last.mesh == 0
 
