@@ -12,8 +12,11 @@
 #include "host_scene.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
+#include <chrono>
 #include <thread>
 
 namespace rayca {
@@ -750,6 +753,16 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     }
   }
   for (HostPrim& p : s.prims) cache_world(p, s.world_trs[p.node]);
+  // RAYCA_BUILD_TIMING=1: phase times of the host build on stderr
+  static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rayca build] %-28s %8.1f ms\n", what, std::chrono::duration<float, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
+  lap("flatten + world transforms");
 
   // ---- Tlas::new: one BLAS per model ------------------------------------------------------------
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -773,7 +786,9 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     if (builder == RAYCA_BUILDER_SAH) {
       ref_prims[m] = blas[m].prims;
       build_blas(m, true, ref_prims[m], ref_nodes[m]);   // the reference's tree: tie order + candidate filter
+      lap("reference tree (ranks, leaves)");
       build_blas(m, false, blas[m].prims, blas[m].nodes);
+      lap("SAH tree");
     } else {
       build_blas(m, true, blas[m].prims, blas[m].nodes);
     }
@@ -804,6 +819,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   }
   for (uint32_t b : blas_order) s.blas.push_back(std::move(blas[b]));
 
+  lap("TLAS + reference tables");
   // ---- device layout ----------------------------------------------------------------------------
   s.dev_nodes.clear();
   s.prim_order.clear();
@@ -848,6 +864,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       }
     }
   }
+  lap("device node layouts");
   return RAYCA_OK;
 }
 

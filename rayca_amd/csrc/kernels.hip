@@ -460,9 +460,14 @@ __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, c
   // normal: primitive.rs:172-182 -> material/mod.rs:125-139 -> pbr.rs:104-123
   F4 normal;
   F4 point = ray.o + ray.d * hit.t;  // Hit.point  triangle.rs:122
+  F4 hit_dir = ray.d;                // Hit.ray.dir
   if (is_sphere) {  // primitive.rs:183-190 and sphere.rs:155-163
     const DevSphere& sp = sc.spheres[e.node];
     const DRay l = sphere_local_ray(sp, ray);
+    // Sphere::intersects builds its Hit from the INVERSE-TRANSFORMED ray (sphere.rs:138,157-159): everything
+    // HitInfo later derives from hit.ray -- view vector, reflection, the transmitted ray -- is in the sphere's
+    // model space.  Reproduced as is.
+    hit_dir = l.d;
     const F4 model_point = l.o + l.d * hit.t;
     const Trs wt{f4(sp.translation[0], sp.translation[1], sp.translation[2], 0.0f), f4(sp.rotation[0], sp.rotation[1], sp.rotation[2], sp.rotation[3]),
                  f4(sp.scale[0], sp.scale[1], sp.scale[2], 0.0f)};
@@ -487,7 +492,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, c
   }
   cx.normal = normal;
   cx.point = point;
-  cx.view = -ray.d;                  // ray.rs:149-151
+  cx.view = -hit_dir;                // ray.rs:149-151
   cx.next_origin = cx.point + normal * kRayBias;  // hit.rs:164-171
   cx.kind = m.kind;
   cx.shininess = m.shininess;

@@ -68,7 +68,21 @@ def glass_scene():
     return scene
 
 
+def sphere_scenes(with_boxes):
+    import test_gpu_parity as P
+    return P._sphere_scene(with_boxes)
+
+
+def textured_scene():
+    """A quad with an albedo + normal texture in front of the box: HitInfo's texture paths under the stack machine."""
+    import test_gpu_parity as P
+    return P._textured_quad_scene()
+
+
 SCENES = {
+    "sphere": lambda: sphere_scenes(False),
+    "sphere_boxes": lambda: sphere_scenes(True),
+    "textured": textured_scene,
     "box": scenes.box_scene,
     "cornell": scenes.cornell_scene,
     "room_phong": lambda: quad_light_room("phong"),
@@ -104,6 +118,12 @@ CASES = [
     ("room_ggx", Config(max_depth=3, indirect_sampler=S.Brdf, seed=12), 0.003),
     ("room_ggx", Config(max_depth=2, direct_sampler=S.NONE, indirect_sampler=S.Hemisphere, seed=13), 0.0),
     ("cornell", Config(max_depth=2, samples_per_pixel=4, light_samples=2, gamma=2.2, seed=14), 0.0),
+    # rayca-soft/tests/gltf.rs:10-46 `sphere`: Scratcher without a BVH on the scaled unit sphere
+    ("sphere", Config(bvh=False, integrator=I.Scratcher), 0.0),
+    ("sphere_boxes", Config(integrator=I.Raytracer, max_depth=2), 0.0),
+    ("sphere_boxes", Config(max_depth=3, light_samples=2, seed=15), 0.0),
+    ("textured", Config(integrator=I.Raytracer, max_depth=1), 0.0),
+    ("textured", Config(russian_roulette=True, indirect_sampler=S.Hemisphere, seed=16), 0.0),
 ]
 
 
