@@ -288,7 +288,10 @@ enum {
 typedef struct RaycaBuildOptions {
   uint32_t builder;   /* RAYCA_BUILDER_* */
   uint32_t device;    /* HIP device ordinal */
-  uint32_t reserved[6];
+  /* 1: run the BLAS builder on the host threads instead of the GPU (bvh_build.hip).  Same tree, same boxes,
+   * same primitive order either way (tested); the GPU builder is used from 4096 primitives per BLAS up. */
+  uint32_t build_on_host;
+  uint32_t reserved[5];
 } RaycaBuildOptions;
 
 /* Which rows of the frame this call renders (multi-GPU tile sharding): rows are dealt to `parts`

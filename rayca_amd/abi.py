@@ -176,7 +176,7 @@ class RaycaSceneDesc(C.Structure):
 
 
 class RaycaBuildOptions(C.Structure):
-    _fields_ = [("builder", C.c_uint32), ("device", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("builder", C.c_uint32), ("device", C.c_uint32), ("build_on_host", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class RaycaTile(C.Structure):

@@ -1,0 +1,567 @@
+// bvh_build.hip -- the BLAS builder on the GPU: the same tree and the same primitive order as BlasBuilder in
+// host_scene.cpp, i.e. as Blas::set_primitives_recursive of the reference (rayca-soft/src/bvh/blas.rs:64-123,
+// 261-316), for both seeds of the candidate boxes (RAYCA_BUILDER_REFERENCE / RAYCA_BUILDER_SAH).
+//
+// The reference rebuilds its BVH inside every draw(); its builder is a recursion with an in-place swap
+// partition whose exact element order matters downstream (leaf order = primitive index = the tie rule).  Here the
+// recursion is run level by level, one workgroup per open node:
+//   1. binning: a primitive is left of plane i iff centroid < pos_i and pos_i is monotone in i, so 64 bins per axis
+//      (count + box, LDS atomics on order-preserving integer keys) give every one of the 189 candidates' counts
+//      and boxes exactly (min/max unions are order independent);
+//   2. the 189 costs are evaluated in the reference's order with its arithmetic and strict `<`;
+//   3. the swap partition (blas.rs:279-289) is not run but SOLVED: the loop examines the front stream in
+//      segments L*R and the back stream in segments R*L alternately, which fixes where every element ends up:
+//         left-class at p < nL stays; the k-th right-class in [0,nL) ("hole") goes to n-1 (k = 1) or to one below
+//         the (k-1)-th left-class counted from the back ("filler"); the k-th filler goes to the k-th hole; a
+//         right-class at p > nL moves to p-1; a right-class at p = nL behaves as hole K+1.
+//      Ranks come from block-wide prefix counts, so the permutation is a scatter.
+// Checked bit for bit against the host builder (tree, boxes, order) in tests/test_gpu_parity.py.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "host_scene.hpp"
+
+namespace rayca {
+namespace {
+
+constexpr int kB = 256;
+constexpr uint32_t kSeq = 16;  // subtrees of at most this many primitives are finished by ONE thread (k_build_small)
+
+struct DNode {
+  float a[3], b[3];
+  uint32_t offset, count;
+  int32_t left, right;
+};
+
+struct BuildState {
+  const float* cent[3];  // centroid, SoA, by primitive id
+  const float* bmin[3];
+  const float* bmax[3];
+  uint32_t* order;       // primitive ids, partitioned in place (through tmp)
+  uint32_t* tmp;
+  uint32_t* rank;        // per position: rank of a hole / filler
+  uint32_t* hole_pos;    // per node range: position of the k-th hole
+  uint32_t* filler_pos;  // per node range: position of the k-th filler
+  DNode* nodes;
+  uint32_t* node_count;
+  uint32_t* small_nodes;  // roots of subtrees left to k_build_small, and their levels
+  uint32_t* small_levels;
+  uint32_t* small_count;
+  uint32_t seed_origin, max_depth;
+};
+
+// order-preserving map float -> uint (for LDS atomicMin/atomicMax)
+__device__ __forceinline__ uint32_t enc(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__device__ __forceinline__ float area3(const float* a, const float* b) {  // aabb.rs:20-23
+  const float ex = b[0] - a[0], ey = b[1] - a[1], ez = b[2] - a[2];
+  return ex * ey + ey * ez + ez * ex;
+}
+
+// exclusive prefix count of `flag` over the block (thread order), and the block total
+__device__ __forceinline__ uint32_t block_prefix(bool flag, uint32_t* wave_tot, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(flag);
+  const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();  // wave_tot may still be read from the previous call
+  if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0, tot = 0;
+  for (uint32_t w = 0; w < kB / 64; ++w) {
+    if (w < wave) before += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  total = tot;
+  return before + in_wave;
+}
+
+__global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint32_t level) {
+  __shared__ uint32_t s_cnt[3][64];
+  __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
+  __shared__ float s_pos[3][64];
+  __shared__ float s_cost[3], s_split[3];
+  __shared__ uint32_t s_wave[kB / 64];
+  __shared__ uint32_t s_red[2][2][3];  // [child][min/max][xyz], encoded
+  __shared__ int s_axis;
+  __shared__ float s_best_pos;
+  __shared__ uint32_t s_split_ok, s_left;
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t node_id = active[blockIdx.x];
+  const DNode nd = st.nodes[node_id];
+  const uint32_t off = nd.offset, n = nd.count;
+
+  // ---- 1. bins ----------------------------------------------------------------------------------------------
+  for (uint32_t i = tid; i < 3 * 64; i += kB) {
+    const uint32_t a = i / 64, b = i % 64;
+    s_cnt[a][b] = 0;
+    for (int c = 0; c < 3; ++c) {
+      s_min[a][b][c] = enc(FLT_MAX);
+      s_max[a][b][c] = enc(-FLT_MAX);
+    }
+    const float lo = nd.a[a], hi = nd.b[a];
+    const float scale = (hi - lo) / 64.0f;
+    s_pos[a][b] = b == 0 ? -FLT_MAX : lo + (float)b * scale;
+  }
+  __syncthreads();
+  bool valid[3];
+  for (int a = 0; a < 3; ++a) valid[a] = nd.a[a] != nd.b[a];
+  for (uint32_t s = tid; s < n; s += kB) {
+    const uint32_t id = st.order[off + s];
+    float mn[3], mx[3];
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = st.bmin[c][id];
+      mx[c] = st.bmax[c][id];
+    }
+    for (int a = 0; a < 3; ++a) {
+      if (!valid[a]) continue;
+      const float c = st.cent[a][id];
+      int k;
+      if (c != c) k = 63;
+      else {
+        int lo = 1, hi = 64;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_pos[a][mid] <= c) lo = mid + 1;
+          else hi = mid;
+        }
+        k = lo - 1;
+      }
+      atomicAdd(&s_cnt[a][k], 1u);
+      for (int cc = 0; cc < 3; ++cc) {
+        atomicMin(&s_min[a][k][cc], enc(mn[cc]));
+        atomicMax(&s_max[a][k][cc], enc(mx[cc]));
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. the 63 candidates of each axis (one thread per axis), reference order and arithmetic -----------------
+  if (tid < 3) {
+    const int a = (int)tid;
+    float best = FLT_MAX, best_pos = 0.0f;
+    if (valid[a]) {
+      // prefix boxes/counts: L[i] = seed U bins[0..i-1]; suffix: R[i] = seed U bins[i..63]
+      float rmin[65][3], rmax[65][3];
+      uint32_t rcnt[65];
+      for (int c = 0; c < 3; ++c) {
+        rmin[64][c] = st.seed_origin ? 0.0f : FLT_MAX;
+        rmax[64][c] = st.seed_origin ? 0.0f : -FLT_MAX;
+      }
+      rcnt[64] = 0;
+      for (int b = 63; b >= 0; --b) {
+        rcnt[b] = rcnt[b + 1] + s_cnt[a][b];
+        for (int c = 0; c < 3; ++c) {
+          rmin[b][c] = rmin[b + 1][c];
+          rmax[b][c] = rmax[b + 1][c];
+          if (s_cnt[a][b]) {
+            rmin[b][c] = fminf(rmin[b][c], dec(s_min[a][b][c]));
+            rmax[b][c] = fmaxf(rmax[b][c], dec(s_max[a][b][c]));
+          }
+        }
+      }
+      float lmin[3], lmax[3];
+      for (int c = 0; c < 3; ++c) {
+        lmin[c] = st.seed_origin ? 0.0f : FLT_MAX;
+        lmax[c] = st.seed_origin ? 0.0f : -FLT_MAX;
+      }
+      uint32_t lcnt = 0;
+      for (int i = 1; i < 64; ++i) {
+        const int b = i - 1;  // L[i] adds bin i-1
+        lcnt += s_cnt[a][b];
+        if (s_cnt[a][b])
+          for (int c = 0; c < 3; ++c) {
+            lmin[c] = fminf(lmin[c], dec(s_min[a][b][c]));
+            lmax[c] = fmaxf(lmax[c], dec(s_max[a][b][c]));
+          }
+        if (!st.seed_origin && (lcnt == 0 || rcnt[i] == 0)) continue;
+        float cost = (float)lcnt * area3(lmin, lmax) + (float)rcnt[i] * area3(rmin[i], rmax[i]);
+        if (!(cost > 0.0f)) cost = FLT_MAX;
+        if (cost < best) {
+          best = cost;
+          best_pos = s_pos[a][i];
+        }
+      }
+    }
+    s_cost[a] = best;
+    s_split[a] = best_pos;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float best = FLT_MAX;
+    int axis = 0;
+    float pos = 0.0f;
+    for (int a = 0; a < 3; ++a)
+      if (s_cost[a] < best) {
+        best = s_cost[a];
+        axis = a;
+        pos = s_split[a];
+      }
+    const float no_split = (float)n * area3(nd.a, nd.b);
+    s_axis = axis;
+    s_best_pos = pos;
+    s_split_ok = best > no_split ? 0u : 1u;
+    s_left = 0;
+  }
+  __syncthreads();
+  if (!s_split_ok) return;  // a leaf: primitives stay as they are
+
+  // ---- 3. the swap partition, solved ------------------------------------------------------------------------------
+  const float* cax = st.cent[s_axis];
+  const float pos = s_best_pos;
+  uint32_t part = 0;
+  for (uint32_t s = tid; s < n; s += kB) part += cax[st.order[off + s]] < pos ? 1u : 0u;
+  atomicAdd(&s_left, part);
+  __syncthreads();
+  const uint32_t nl = s_left;
+  if (nl == 0 || nl == n) {
+    // everything on one side.  All left: the loop never swaps.  All right: it rotates the range (first element to
+    // the end, the others down by one) -- and the node stays a leaf either way (blas.rs:291-293).
+    if (nl == 0 && n > 1) {
+      for (uint32_t s = tid; s < n; s += kB) st.tmp[off + (s == 0 ? n - 1 : s - 1)] = st.order[off + s];
+      __syncthreads();
+      for (uint32_t s = tid; s < n; s += kB) st.order[off + s] = st.tmp[off + s];
+    }
+    return;
+  }
+  // holes: right-class at p < nl, ranked ascending
+  uint32_t run = 0;
+  for (uint32_t base = 0; base < nl; base += kB) {
+    const uint32_t p = base + tid;
+    const bool is_hole = p < nl && !(cax[st.order[off + p]] < pos);
+    uint32_t tot;
+    const uint32_t r = run + block_prefix(is_hole, s_wave, tot);
+    if (is_hole) {
+      st.hole_pos[off + r] = p;
+      st.rank[off + p] = r;
+    }
+    run += tot;
+  }
+  const uint32_t K = run;  // holes == fillers
+  // fillers: left-class at p >= nl, ranked descending
+  run = 0;
+  for (uint32_t base = 0; base < n - nl; base += kB) {
+    const uint32_t q = base + tid;            // distance from the end
+    const bool in = q < n - nl;
+    const uint32_t p = in ? n - 1 - q : 0;
+    const bool is_filler = in && cax[st.order[off + p]] < pos;
+    uint32_t tot;
+    const uint32_t r = run + block_prefix(is_filler, s_wave, tot);
+    if (is_filler) {
+      st.filler_pos[off + r] = p;
+      st.rank[off + p] = r;
+    }
+    run += tot;
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < n; p += kB) {
+    const uint32_t id = st.order[off + p];
+    const bool left = cax[id] < pos;
+    uint32_t dest;
+    if (p < nl) {
+      if (left) dest = p;
+      else {
+        const uint32_t k = st.rank[off + p];
+        dest = k == 0 ? n - 1 : st.filler_pos[off + k - 1] - 1;
+      }
+    } else if (left) {
+      dest = st.hole_pos[off + st.rank[off + p]];
+    } else if (p == nl) {
+      dest = (K == 0 ? n : st.filler_pos[off + K - 1]) - 1;
+    } else {
+      dest = p - 1;
+    }
+    st.tmp[off + dest] = id;
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < n; p += kB) st.order[off + p] = st.tmp[off + p];
+  // ---- 4. children --------------------------------------------------------------------------------------------------
+  if (tid < 12) {
+    const uint32_t child = tid / 6, mm = (tid / 3) & 1u, c = tid % 3;
+    s_red[child][mm][c] = mm ? enc(-FLT_MAX) : enc(FLT_MAX);
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < n; p += kB) {
+    const uint32_t id = st.tmp[off + p];
+    const uint32_t child = p < nl ? 0u : 1u;
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&s_red[child][0][c], enc(st.bmin[c][id]));
+      atomicMax(&s_red[child][1][c], enc(st.bmax[c][id]));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t base = atomicAdd(st.node_count, 2u);
+    DNode l, r;
+    for (int c = 0; c < 3; ++c) {
+      l.a[c] = dec(s_red[0][0][c]); l.b[c] = dec(s_red[0][1][c]);
+      r.a[c] = dec(s_red[1][0][c]); r.b[c] = dec(s_red[1][1][c]);
+    }
+    l.offset = off; l.count = nl; l.left = l.right = -1;
+    r.offset = off + nl; r.count = n - nl; r.left = r.right = -1;
+    st.nodes[base] = l;
+    st.nodes[base + 1] = r;
+    st.nodes[node_id].left = (int32_t)base;
+    st.nodes[node_id].right = (int32_t)base + 1;
+    st.nodes[node_id].count = 0;  // inner
+    for (uint32_t c = 0; c < 2; ++c) {
+      const uint32_t cn = c ? n - nl : nl;
+      if (cn <= kSeq) {
+        if (cn > 1) {  // a single primitive can never be split: nothing left to do
+          const uint32_t slot = atomicAdd(st.small_count, 1u);
+          st.small_nodes[slot] = base + c;
+          st.small_levels[slot] = level + 1u;
+        }
+      } else {
+        next[atomicAdd(next_count, 1u)] = base + c;
+      }
+    }
+  }
+}
+
+// A subtree of at most kSeq primitives, finished by one thread: the reference's recursion as it stands -- every
+// candidate plane evaluated by a loop over the primitives (evaluate_sah, blas.rs:64-89: the same counts and boxes
+// the bins give, min/max being order independent), the swap partition run literally (blas.rs:279-289).
+__global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_small) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_small) return;
+  const uint32_t root = st.small_nodes[t];
+  const uint32_t root_level = st.small_levels[t];
+  const uint32_t base_off = st.nodes[root].offset, total = st.nodes[root].count;
+  uint32_t ids[kSeq];
+  float cen[3][kSeq], mn[3][kSeq], mx[3][kSeq];
+  for (uint32_t i = 0; i < total; ++i) {
+    const uint32_t id = st.order[base_off + i];
+    ids[i] = id;
+    for (int c = 0; c < 3; ++c) {
+      cen[c][i] = st.cent[c][id];
+      mn[c][i] = st.bmin[c][id];
+      mx[c][i] = st.bmax[c][id];
+    }
+  }
+  uint32_t stack_node[kSeq + 1], stack_level[kSeq + 1];
+  int sp = 0;
+  stack_node[0] = root;
+  stack_level[0] = root_level;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    const uint32_t node_id = stack_node[sp], level = stack_level[sp];
+    if (level >= st.max_depth) continue;
+    const DNode nd = st.nodes[node_id];
+    const uint32_t lo = nd.offset - base_off, n = nd.count;
+    // find_best_split_plane  blas.rs:93-123
+    float best = FLT_MAX, best_pos = 0.0f;
+    int best_axis = 0;
+    for (int a = 0; a < 3; ++a) {
+      const float bmin = nd.a[a], bmax = nd.b[a];
+      if (bmin == bmax) continue;
+      const float scale = (bmax - bmin) / 64.0f;
+      for (int i = 1; i < 64; ++i) {
+        const float pos = bmin + (float)i * scale;
+        float la[3], lb[3], ra[3], rb[3];
+        for (int c = 0; c < 3; ++c) {
+          la[c] = ra[c] = st.seed_origin ? 0.0f : FLT_MAX;
+          lb[c] = rb[c] = st.seed_origin ? 0.0f : -FLT_MAX;
+        }
+        uint32_t lc = 0, rc = 0;
+        for (uint32_t k = lo; k < lo + n; ++k) {
+          if (cen[a][k] < pos) {
+            ++lc;
+            for (int c = 0; c < 3; ++c) {
+              la[c] = fminf(la[c], mn[c][k]);
+              lb[c] = fmaxf(lb[c], mx[c][k]);
+            }
+          } else {
+            ++rc;
+            for (int c = 0; c < 3; ++c) {
+              ra[c] = fminf(ra[c], mn[c][k]);
+              rb[c] = fmaxf(rb[c], mx[c][k]);
+            }
+          }
+        }
+        if (!st.seed_origin && (lc == 0 || rc == 0)) continue;
+        float cost = (float)lc * area3(la, lb) + (float)rc * area3(ra, rb);
+        if (!(cost > 0.0f)) cost = FLT_MAX;
+        if (cost < best) {
+          best = cost;
+          best_axis = a;
+          best_pos = pos;
+        }
+      }
+    }
+    const float no_split = (float)n * area3(nd.a, nd.b);
+    if (best > no_split) continue;
+    // the swap partition, literally
+    uint32_t i = lo, j = lo + n;
+    while (i < j) {
+      if (cen[best_axis][i] < best_pos) {
+        ++i;
+      } else {
+        const uint32_t q = j - 1;
+        const uint32_t tid_ = ids[i]; ids[i] = ids[q]; ids[q] = tid_;
+        for (int c = 0; c < 3; ++c) {
+          float f = cen[c][i]; cen[c][i] = cen[c][q]; cen[c][q] = f;
+          f = mn[c][i]; mn[c][i] = mn[c][q]; mn[c][q] = f;
+          f = mx[c][i]; mx[c][i] = mx[c][q]; mx[c][q] = f;
+        }
+        --j;
+      }
+    }
+    const uint32_t nl = i - lo, nr = n - nl;
+    if (nl == 0 || nr == 0) continue;
+    const uint32_t base = atomicAdd(st.node_count, 2u);
+    DNode l, r;
+    for (int c = 0; c < 3; ++c) {
+      l.a[c] = FLT_MAX; l.b[c] = -FLT_MAX;
+      r.a[c] = FLT_MAX; r.b[c] = -FLT_MAX;
+    }
+    for (uint32_t k = lo; k < lo + nl; ++k)
+      for (int c = 0; c < 3; ++c) {
+        l.a[c] = fminf(l.a[c], mn[c][k]);
+        l.b[c] = fmaxf(l.b[c], mx[c][k]);
+      }
+    for (uint32_t k = lo + nl; k < lo + n; ++k)
+      for (int c = 0; c < 3; ++c) {
+        r.a[c] = fminf(r.a[c], mn[c][k]);
+        r.b[c] = fmaxf(r.b[c], mx[c][k]);
+      }
+    l.offset = nd.offset; l.count = nl; l.left = l.right = -1;
+    r.offset = nd.offset + nl; r.count = nr; r.left = r.right = -1;
+    st.nodes[base] = l;
+    st.nodes[base + 1] = r;
+    st.nodes[node_id].left = (int32_t)base;
+    st.nodes[node_id].right = (int32_t)base + 1;
+    st.nodes[node_id].count = 0;
+    if (nr > 1) { stack_node[sp] = base + 1; stack_level[sp] = level + 1; ++sp; }
+    if (nl > 1) { stack_node[sp] = base; stack_level[sp] = level + 1; ++sp; }
+  }
+  for (uint32_t i = 0; i < total; ++i) st.order[base_off + i] = ids[i];
+}
+
+#define HB_TRY(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) {                                                               \
+      err = std::string("gpu bvh build: ") + #expr + ": " + hipGetErrorString(e__);        \
+      cleanup();                                                                           \
+      return false;                                                                        \
+    }                                                                                      \
+  } while (0)
+
+}  // namespace
+
+// BlasBuildFn: see host_scene.hpp
+bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err) {
+  const uint32_t n = in.count;
+  std::vector<void*> allocs;
+  auto cleanup = [&] {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+  };
+  auto dalloc = [&](size_t bytes, void** out) -> hipError_t {
+    hipError_t e = hipMalloc(out, bytes ? bytes : 4);
+    if (e == hipSuccess) allocs.push_back(*out);
+    return e;
+  };
+  HB_TRY(hipSetDevice((int)in.device));
+  BuildState st{};
+  float* f[9];
+  for (int i = 0; i < 9; ++i) {
+    void* p = nullptr;
+    HB_TRY(dalloc(sizeof(float) * n, &p));
+    f[i] = static_cast<float*>(p);
+  }
+  const float* src[9] = {in.cent[0], in.cent[1], in.cent[2], in.bmin[0], in.bmin[1], in.bmin[2], in.bmax[0], in.bmax[1], in.bmax[2]};
+  for (int i = 0; i < 9; ++i) HB_TRY(hipMemcpy(f[i], src[i], sizeof(float) * n, hipMemcpyHostToDevice));
+  for (int c = 0; c < 3; ++c) {
+    st.cent[c] = f[c];
+    st.bmin[c] = f[3 + c];
+    st.bmax[c] = f[6 + c];
+  }
+  uint32_t* u[9];
+  for (int i = 0; i < 9; ++i) {
+    void* p = nullptr;
+    HB_TRY(dalloc(sizeof(uint32_t) * ((size_t)n + 2), &p));
+    u[i] = static_cast<uint32_t*>(p);
+  }
+  st.order = u[0]; st.tmp = u[1]; st.rank = u[2]; st.hole_pos = u[3]; st.filler_pos = u[4];
+  uint32_t* lists[2] = {u[5], u[6]};
+  st.small_nodes = u[7];
+  st.small_levels = u[8];
+  void* pn = nullptr;
+  HB_TRY(dalloc(sizeof(DNode) * (2 * (size_t)n + 2), &pn));
+  st.nodes = static_cast<DNode*>(pn);
+  void* pc = nullptr;
+  HB_TRY(dalloc(64, &pc));
+  st.node_count = static_cast<uint32_t*>(pc);
+  uint32_t* next_count = st.node_count + 1;
+  st.small_count = st.node_count + 2;
+  st.seed_origin = in.seed_origin ? 1u : 0u;
+  st.max_depth = in.max_depth;
+
+  std::vector<uint32_t> ident(n);
+  for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+  HB_TRY(hipMemcpy(st.order, ident.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  DNode root{};
+  for (int c = 0; c < 3; ++c) {
+    root.a[c] = in.root_min[c];
+    root.b[c] = in.root_max[c];
+  }
+  root.offset = 0; root.count = n; root.left = root.right = -1;
+  HB_TRY(hipMemcpy(st.nodes, &root, sizeof root, hipMemcpyHostToDevice));
+  const uint32_t init[3] = {1u, 0u, 0u};
+  HB_TRY(hipMemcpy(st.node_count, init, sizeof init, hipMemcpyHostToDevice));
+  const uint32_t zero = 0;
+  HB_TRY(hipMemcpy(lists[0], &zero, 4, hipMemcpyHostToDevice));  // level 0: the root
+
+  static const bool verbose = getenv("RAYCA_BUILD_TIMING") != nullptr;
+  uint32_t n_active = n > 0 ? 1u : 0u;
+  uint32_t levels_run = 0, blocks_run = 0;
+  for (uint32_t level = 0; level < in.max_depth && n_active > 0; ++level) {
+    ++levels_run;
+    blocks_run += n_active;
+    HB_TRY(hipMemset(next_count, 0, 4));
+    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(kB), 0, 0, st, lists[level & 1], lists[(level + 1) & 1], next_count, level);
+    HB_TRY(hipGetLastError());
+    HB_TRY(hipMemcpy(&n_active, next_count, 4, hipMemcpyDeviceToHost));
+  }
+  uint32_t n_small = 0;
+  HB_TRY(hipMemcpy(&n_small, st.small_count, 4, hipMemcpyDeviceToHost));
+  if (verbose) fprintf(stderr, "[rayca build]   gpu: %u primitives, %u levels, %u node blocks, %u small subtrees\n", n, levels_run, blocks_run, n_small);
+  if (n_small) {
+    hipLaunchKernelGGL(k_build_small, dim3((n_small + 63) / 64), dim3(64), 0, 0, st, n_small);
+    HB_TRY(hipGetLastError());
+  }
+  uint32_t node_count = 0;
+  HB_TRY(hipMemcpy(&node_count, st.node_count, 4, hipMemcpyDeviceToHost));
+  std::vector<DNode> nodes(node_count);
+  HB_TRY(hipMemcpy(nodes.data(), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost));
+  order.resize(n);
+  HB_TRY(hipMemcpy(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  arena.resize(node_count);
+  for (uint32_t i = 0; i < node_count; ++i) {
+    for (int c = 0; c < 3; ++c) {
+      arena[i].a[c] = nodes[i].a[c];
+      arena[i].b[c] = nodes[i].b[c];
+    }
+    arena[i].offset = nodes[i].offset;
+    arena[i].count = nodes[i].count;
+    arena[i].left = nodes[i].left;
+    arena[i].right = nodes[i].right;
+  }
+  cleanup();
+  return true;
+}
+
+}  // namespace rayca

@@ -86,6 +86,11 @@ void cache_world(HostPrim& p, const Trs& t) {
 }
 
 // ---- BLAS build --------------------------------------------------------------------------------
+thread_local BlasBuildFn g_device_builder = nullptr;  // per thread: scenes may be created concurrently on different devices
+thread_local uint32_t g_device_ordinal = 0;
+// below this many primitives the host builder is faster than a level-by-level sequence of launches
+constexpr uint32_t kDeviceBuildMin = 4096;
+
 struct BuildNode {
   Box bounds;
   uint32_t offset = 0, count = 0;  // primitive range (leaf) -- count == 0 => inner
@@ -587,6 +592,11 @@ void set_ext(PrimExt& e, int k, Color c, F4 n, F4 t, F4 b, F2 uv) {
 
 }  // namespace
 
+void set_device_blas_builder(BlasBuildFn fn, uint32_t device) {
+  g_device_builder = fn;
+  g_device_ordinal = device;
+}
+
 int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err) {
   if (d.abi_version != RAYCA_ABI_VERSION) { err = "abi version mismatch"; return RAYCA_ERR_BAD_ARG; }
   if (d.node_count && !d.nodes) { err = "nodes is null"; return RAYCA_ERR_BAD_ARG; }
@@ -772,25 +782,68 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   // reference order of every primitive inside its BLAS (needed by both builders: it is the tie rule)
   std::vector<std::vector<uint32_t>> ref_prims(blas.size());
   std::vector<std::vector<RefNode>> ref_nodes(blas.size());
+  static const bool host_only = getenv("RAYCA_HOST_BUILD") != nullptr;
+  std::string build_err;
   auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<RefNode>& nodes) {
     BlasBuilder bb{&s, &order, use_bvh ? 255u : 0u, par_levels + 1, seed_origin};
     std::vector<BuildNode> arena(1);
     arena[0].offset = 0;
     arena[0].count = (uint32_t)order.size();
     arena[0].bounds = bb.range_bounds(0, arena[0].count);
-    if (arena[0].count > 0) bb.split(arena, 0, 0);
+    const uint32_t n = arena[0].count;
+    if (g_device_builder && !host_only && use_bvh && n >= kDeviceBuildMin) {
+      // the same recursion, level by level on the GPU (bvh_build.hip): identical tree, boxes and order
+      std::vector<float> soa[9];
+      for (auto& v : soa) v.resize(n);
+      for (uint32_t i = 0; i < n; ++i) {
+        const HostPrim& p = s.prims[order[i]];
+        soa[0][i] = p.wcentroid.x; soa[1][i] = p.wcentroid.y; soa[2][i] = p.wcentroid.z;
+        soa[3][i] = p.wmin.x; soa[4][i] = p.wmin.y; soa[5][i] = p.wmin.z;
+        soa[6][i] = p.wmax.x; soa[7][i] = p.wmax.y; soa[8][i] = p.wmax.z;
+      }
+      BlasBuildInput in{};
+      for (int c = 0; c < 3; ++c) {
+        in.cent[c] = soa[c].data();
+        in.bmin[c] = soa[3 + c].data();
+        in.bmax[c] = soa[6 + c].data();
+      }
+      in.count = n;
+      in.root_min[0] = arena[0].bounds.a.x; in.root_min[1] = arena[0].bounds.a.y; in.root_min[2] = arena[0].bounds.a.z;
+      in.root_max[0] = arena[0].bounds.b.x; in.root_max[1] = arena[0].bounds.b.y; in.root_max[2] = arena[0].bounds.b.z;
+      in.seed_origin = seed_origin;
+      in.max_depth = 255u;
+      in.device = g_device_ordinal;
+      std::vector<uint32_t> perm;
+      std::vector<BlasBuildNode> dn;
+      if (!g_device_builder(in, perm, dn, build_err)) return false;
+      std::vector<uint32_t> permuted(n);
+      for (uint32_t i = 0; i < n; ++i) permuted[i] = order[perm[i]];
+      order.swap(permuted);
+      arena.resize(dn.size());
+      for (size_t i = 0; i < dn.size(); ++i) {
+        arena[i].bounds = Box{point3(dn[i].a[0], dn[i].a[1], dn[i].a[2]), point3(dn[i].b[0], dn[i].b[1], dn[i].b[2])};
+        arena[i].offset = dn[i].offset;
+        arena[i].count = dn[i].count;
+        arena[i].left = dn[i].left;
+        arena[i].right = dn[i].right;
+      }
+    } else if (n > 0) {
+      bb.split(arena, 0, 0);
+    }
     to_reference_layout(arena, nodes);
     blas_root[m] = arena[0].bounds;
+    return true;
   };
   for (size_t m = 0; m < blas.size(); ++m) {
     if (builder == RAYCA_BUILDER_SAH) {
       ref_prims[m] = blas[m].prims;
-      build_blas(m, true, ref_prims[m], ref_nodes[m]);   // the reference's tree: tie order + candidate filter
+      bool ok = build_blas(m, true, ref_prims[m], ref_nodes[m]);   // the reference's tree: tie order + candidate filter
       lap("reference tree (ranks, leaves)");
-      build_blas(m, false, blas[m].prims, blas[m].nodes);
+      ok = ok && build_blas(m, false, blas[m].prims, blas[m].nodes);
       lap("SAH tree");
+      if (!ok) { err = build_err; return RAYCA_ERR_HIP; }
     } else {
-      build_blas(m, true, blas[m].prims, blas[m].nodes);
+      if (!build_blas(m, true, blas[m].prims, blas[m].nodes)) { err = build_err; return RAYCA_ERR_HIP; }
     }
   }
   std::vector<uint32_t> blas_order(blas.size());

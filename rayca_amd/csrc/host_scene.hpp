@@ -115,4 +115,25 @@ struct HostScene {
 // Returns RAYCA_OK or an error code with `err` filled.
 int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err);
 
+// Device BLAS builder (bvh_build.hip): the same tree and primitive order as the host builder, built on the GPU.
+// host_scene.cpp does not link HIP; the library registers the function before it builds a scene.
+struct BlasBuildInput {
+  const float* cent[3];   // world centroids, SoA, `count` entries (host memory)
+  const float* bmin[3];   // world boxes
+  const float* bmax[3];
+  uint32_t count;
+  float root_min[3], root_max[3];
+  bool seed_origin;       // candidate boxes start at the origin (the reference) or empty (RAYCA_BUILDER_SAH)
+  uint32_t max_depth;
+  uint32_t device;
+};
+struct BlasBuildNode {
+  float a[3], b[3];
+  uint32_t offset, count;  // count == 0: inner
+  int32_t left, right;
+};
+using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
+void set_device_blas_builder(BlasBuildFn fn, uint32_t device);
+bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
+
 }  // namespace rayca

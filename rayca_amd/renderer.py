@@ -49,12 +49,12 @@ class DeviceScene:
     """Owns a RaycaScene handle: the device-resident scene + BVH (first half of draw, scene.rs:90-99)."""
 
     def __init__(self, desc: abi.SceneDesc, config: Optional[Config] = None, device: int = 0,
-                 builder: int = abi.BUILDER_REFERENCE, _lib=None):
+                 builder: int = abi.BUILDER_REFERENCE, build_on_host: bool = False, _lib=None):
         self._lib = _lib or lib.load()  # _lib: an explicitly loaded build of the library (A/B experiments)
         self.desc = desc
         cfg = (config or Config()).to_abi()
         opts = abi.RaycaBuildOptions()
-        opts.builder, opts.device = builder, device
+        opts.builder, opts.device, opts.build_on_host = builder, device, int(build_on_host)
         h = C.c_void_p()
         lib.check(self._lib.rayca_hip_scene_create(desc.ptr(), C.byref(cfg), C.byref(opts), C.byref(h)))
         self.handle = h

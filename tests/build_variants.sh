@@ -5,10 +5,11 @@ cd "$(dirname "$0")/../rayca_amd/csrc"
 mkdir -p variants
 COMMON="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result"
 [ -f host_scene.o ] || g++ $COMMON -c host_scene.cpp -o host_scene.o -pthread
+[ -f bvh_build.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 $COMMON -c bvh_build.hip -o bvh_build.o
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $COMMON $flags -c kernels.hip -o variants/$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC variants/$name.o host_scene.o -o variants/librayca_$name.so -lpthread
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC variants/$name.o bvh_build.o host_scene.o -o variants/librayca_$name.so -lpthread
   rm variants/$name.o
   echo built $name
 done
