@@ -211,7 +211,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": wl["label"], "width": W, "height": H, "triangles": info["triangle_count"],
-                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1),
+                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
                    "node_format": {"generation0": "4-wide" if node_format & 1 else "binary", "bounces": "4-wide" if node_format & 2 else "binary", "chosen_by": "timing both on this scene"},
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
