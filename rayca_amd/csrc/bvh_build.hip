@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -31,12 +32,16 @@ namespace rayca {
 namespace {
 
 constexpr int kB = 256;
+constexpr uint32_t kBig = 16384;    // nodes above this size are binned by many workgroups (k_bin_big), kChunk positions each
+constexpr uint32_t kChunk = 4096;
+constexpr uint32_t kBinWords = 3 * 64 * 7;  // per node: count + min xyz + max xyz for 64 bins on 3 axes
 constexpr uint32_t kSeq = 16;  // subtrees of at most this many primitives are finished by ONE thread (k_build_small)
 
 struct DNode {
   float a[3], b[3];
   uint32_t offset, count;
   int32_t left, right;
+  uint32_t big;  // slot of this node's bins in BuildState::gbins when it was binned by k_bin_big, else RAYCA_NONE
 };
 
 struct BuildState {
@@ -54,6 +59,10 @@ struct BuildState {
   uint32_t* small_levels;
   uint32_t* small_count;
   uint32_t seed_origin, max_depth;
+  uint32_t* gbins;        // [big slot][kBinWords]: bins of the big nodes of the current level
+  uint2* chunks[2];       // (node, chunk index) work list of k_bin_big, this level / next level
+  uint32_t* chunk_count;  // entries appended to the next level's list
+  uint32_t* slot_count;   // big slots handed out for the next level
 };
 
 // order-preserving map float -> uint (for LDS atomicMin/atomicMax)
@@ -85,24 +94,8 @@ __device__ __forceinline__ uint32_t block_prefix(bool flag, uint32_t* wave_tot, 
   return before + in_wave;
 }
 
-__global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint32_t level) {
-  __shared__ uint32_t s_cnt[3][64];
-  __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
-  __shared__ float s_pos[3][64];
-  __shared__ float s_cost[3], s_split[3];
-  __shared__ uint32_t s_wave[kB / 64];
-  __shared__ uint32_t s_red[2][2][3];  // [child][min/max][xyz], encoded
-  __shared__ int s_axis;
-  __shared__ float s_best_pos;
-  __shared__ uint32_t s_split_ok, s_left;
-
-  const uint32_t tid = threadIdx.x;
-  const uint32_t node_id = active[blockIdx.x];
-  const DNode nd = st.nodes[node_id];
-  const uint32_t off = nd.offset, n = nd.count;
-
-  // ---- 1. bins ----------------------------------------------------------------------------------------------
-  for (uint32_t i = tid; i < 3 * 64; i += kB) {
+__device__ __forceinline__ void init_bins(const DNode& nd, uint32_t (*s_cnt)[64], uint32_t (*s_min)[64][3], uint32_t (*s_max)[64][3], float (*s_pos)[64]) {
+  for (uint32_t i = threadIdx.x; i < 3 * 64; i += kB) {
     const uint32_t a = i / 64, b = i % 64;
     s_cnt[a][b] = 0;
     for (int c = 0; c < 3; ++c) {
@@ -113,11 +106,13 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
     const float scale = (hi - lo) / 64.0f;
     s_pos[a][b] = b == 0 ? -FLT_MAX : lo + (float)b * scale;
   }
-  __syncthreads();
-  bool valid[3];
-  for (int a = 0; a < 3; ++a) valid[a] = nd.a[a] != nd.b[a];
-  for (uint32_t s = tid; s < n; s += kB) {
-    const uint32_t id = st.order[off + s];
+}
+
+// positions [begin, end) of the node's range into the 3 x 64 bins
+__device__ __forceinline__ void bin_range(const BuildState& st, const DNode& nd, const bool* valid, uint32_t (*s_cnt)[64], uint32_t (*s_min)[64][3],
+                                          uint32_t (*s_max)[64][3], float (*s_pos)[64], uint32_t begin, uint32_t end) {
+  for (uint32_t s = begin + threadIdx.x; s < end; s += kB) {
+    const uint32_t id = st.order[nd.offset + s];
     float mn[3], mx[3];
     for (int c = 0; c < 3; ++c) {
       mn[c] = st.bmin[c][id];
@@ -143,6 +138,78 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
         atomicMax(&s_max[a][k][cc], enc(mx[cc]));
       }
     }
+  }
+}
+
+// bins of the big nodes: one workgroup per kChunk positions, merged into the node's global bins
+__global__ __launch_bounds__(kB) void k_bin_init(BuildState st, uint32_t slots) {
+  const uint32_t i = blockIdx.x * kB + threadIdx.x;
+  if (i >= slots * 3 * 64) return;
+  uint32_t* g = st.gbins + (size_t)i * 7;
+  g[0] = 0;
+  for (int c = 0; c < 3; ++c) {
+    g[1 + c] = enc(FLT_MAX);
+    g[4 + c] = enc(-FLT_MAX);
+  }
+}
+__global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chunks) {
+  __shared__ uint32_t s_cnt[3][64];
+  __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
+  __shared__ float s_pos[3][64];
+  const uint2 job = chunks[blockIdx.x];
+  const DNode nd = st.nodes[job.x];
+  init_bins(nd, s_cnt, s_min, s_max, s_pos);
+  __syncthreads();
+  bool valid[3];
+  for (int a = 0; a < 3; ++a) valid[a] = nd.a[a] != nd.b[a];
+  const uint32_t begin = job.y * kChunk, end = min(nd.count, begin + kChunk);
+  bin_range(st, nd, valid, s_cnt, s_min, s_max, s_pos, begin, end);
+  __syncthreads();
+  uint32_t* g = st.gbins + (size_t)nd.big * kBinWords;
+  for (uint32_t i = threadIdx.x; i < 3 * 64; i += kB) {
+    const uint32_t a = i / 64, b = i % 64;
+    if (s_cnt[a][b] == 0) continue;
+    atomicAdd(&g[i * 7], s_cnt[a][b]);
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&g[i * 7 + 1 + c], s_min[a][b][c]);
+      atomicMax(&g[i * 7 + 4 + c], s_max[a][b][c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level) {
+  __shared__ uint32_t s_cnt[3][64];
+  __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
+  __shared__ float s_pos[3][64];
+  __shared__ float s_cost[3], s_split[3];
+  __shared__ uint32_t s_wave[kB / 64];
+  __shared__ uint32_t s_red[2][2][3];  // [child][min/max][xyz], encoded
+  __shared__ int s_axis;
+  __shared__ float s_best_pos;
+  __shared__ uint32_t s_split_ok, s_left;
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t node_id = active[blockIdx.x];
+  const DNode nd = st.nodes[node_id];
+  const uint32_t off = nd.offset, n = nd.count;
+
+  // ---- 1. bins ----------------------------------------------------------------------------------------------
+  init_bins(nd, s_cnt, s_min, s_max, s_pos);
+  __syncthreads();
+  bool valid[3];
+  for (int a = 0; a < 3; ++a) valid[a] = nd.a[a] != nd.b[a];
+  if (nd.big != RAYCA_NONE) {  // binned by k_bin_big: fetch
+    const uint32_t* g = st.gbins + (size_t)nd.big * kBinWords;
+    for (uint32_t i = tid; i < 3 * 64; i += kB) {
+      const uint32_t a = i / 64, b = i % 64;
+      s_cnt[a][b] = g[i * 7];
+      for (int c = 0; c < 3; ++c) {
+        s_min[a][b][c] = g[i * 7 + 1 + c];
+        s_max[a][b][c] = g[i * 7 + 4 + c];
+      }
+    }
+  } else {
+    bin_range(st, nd, valid, s_cnt, s_min, s_max, s_pos, 0, n);
   }
   __syncthreads();
 
@@ -309,6 +376,15 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
     }
     l.offset = off; l.count = nl; l.left = l.right = -1;
     r.offset = off + nl; r.count = n - nl; r.left = r.right = -1;
+    l.big = nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE;
+    r.big = n - nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE;
+    for (uint32_t c = 0; c < 2; ++c) {
+      const DNode& ch = c ? r : l;
+      if (ch.big == RAYCA_NONE) continue;
+      const uint32_t nch = (ch.count + kChunk - 1) / kChunk;
+      const uint32_t at = atomicAdd(st.chunk_count, nch);
+      for (uint32_t k = 0; k < nch; ++k) next_chunks[at + k] = make_uint2(base + c, k);
+    }
     st.nodes[base] = l;
     st.nodes[base + 1] = r;
     st.nodes[node_id].left = (int32_t)base;
@@ -436,8 +512,8 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_sm
         r.a[c] = fminf(r.a[c], mn[c][k]);
         r.b[c] = fmaxf(r.b[c], mx[c][k]);
       }
-    l.offset = nd.offset; l.count = nl; l.left = l.right = -1;
-    r.offset = nd.offset + nl; r.count = nr; r.left = r.right = -1;
+    l.offset = nd.offset; l.count = nl; l.left = l.right = -1; l.big = RAYCA_NONE;
+    r.offset = nd.offset + nl; r.count = nr; r.left = r.right = -1; r.big = RAYCA_NONE;
     st.nodes[base] = l;
     st.nodes[base + 1] = r;
     st.nodes[node_id].left = (int32_t)base;
@@ -474,6 +550,15 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     if (e == hipSuccess) allocs.push_back(*out);
     return e;
   };
+  static const bool verbose = getenv("RAYCA_BUILD_TIMING") != nullptr;
+  auto tp = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rayca build]     gpu %-22s %7.2f ms\n", what, std::chrono::duration<float, std::milli>(now - tp).count());
+    tp = now;
+  };
   HB_TRY(hipSetDevice((int)in.device));
   BuildState st{};
   float* f[9];
@@ -505,6 +590,17 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   void* pc = nullptr;
   HB_TRY(dalloc(64, &pc));
   st.node_count = static_cast<uint32_t*>(pc);
+  st.chunk_count = st.node_count + 3;
+  st.slot_count = st.node_count + 4;
+  const uint32_t max_slots = n / kBig + 2, max_chunks = n / kChunk + max_slots + 2;
+  void* pg = nullptr;
+  HB_TRY(dalloc((size_t)max_slots * kBinWords * 4, &pg));
+  st.gbins = static_cast<uint32_t*>(pg);
+  for (int i = 0; i < 2; ++i) {
+    void* pch = nullptr;
+    HB_TRY(dalloc((size_t)max_chunks * sizeof(uint2), &pch));
+    st.chunks[i] = static_cast<uint2*>(pch);
+  }
   uint32_t* next_count = st.node_count + 1;
   st.small_count = st.node_count + 2;
   st.seed_origin = in.seed_origin ? 1u : 0u;
@@ -519,23 +615,54 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     root.b[c] = in.root_max[c];
   }
   root.offset = 0; root.count = n; root.left = root.right = -1;
+  root.big = n > kBig ? 0u : RAYCA_NONE;
   HB_TRY(hipMemcpy(st.nodes, &root, sizeof root, hipMemcpyHostToDevice));
-  const uint32_t init[3] = {1u, 0u, 0u};
+  const uint32_t init[5] = {1u, 0u, 0u, 0u, 0u};
   HB_TRY(hipMemcpy(st.node_count, init, sizeof init, hipMemcpyHostToDevice));
   const uint32_t zero = 0;
   HB_TRY(hipMemcpy(lists[0], &zero, 4, hipMemcpyHostToDevice));  // level 0: the root
 
-  static const bool verbose = getenv("RAYCA_BUILD_TIMING") != nullptr;
+  lap("alloc + upload");
   uint32_t n_active = n > 0 ? 1u : 0u;
+  uint32_t n_chunks = 0, n_slots = 0;
+  if (n > kBig) {  // the root's chunks
+    n_slots = 1;
+    n_chunks = (n + kChunk - 1) / kChunk;
+    std::vector<uint2> rc(n_chunks);
+    for (uint32_t k = 0; k < n_chunks; ++k) rc[k] = make_uint2(0u, k);
+    HB_TRY(hipMemcpy(st.chunks[0], rc.data(), sizeof(uint2) * n_chunks, hipMemcpyHostToDevice));
+  }
   uint32_t levels_run = 0, blocks_run = 0;
   for (uint32_t level = 0; level < in.max_depth && n_active > 0; ++level) {
     ++levels_run;
     blocks_run += n_active;
+    const auto lt0 = std::chrono::steady_clock::now();
+    const uint32_t blocks_this_level = n_active;
+    if (n_chunks) {  // big nodes of this level: bins by many workgroups
+      hipLaunchKernelGGL(k_bin_init, dim3((n_slots * 3 * 64 + kB - 1) / kB), dim3(kB), 0, 0, st, n_slots);
+      hipLaunchKernelGGL(k_bin_big, dim3(n_chunks), dim3(kB), 0, 0, st, st.chunks[level & 1]);
+      HB_TRY(hipGetLastError());
+    }
     HB_TRY(hipMemset(next_count, 0, 4));
-    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(kB), 0, 0, st, lists[level & 1], lists[(level + 1) & 1], next_count, level);
+    HB_TRY(hipMemset(st.chunk_count, 0, 8));  // chunk_count, slot_count
+    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(kB), 0, 0, st, lists[level & 1], lists[(level + 1) & 1], next_count,
+                       st.chunks[(level + 1) & 1], level);
     HB_TRY(hipGetLastError());
-    HB_TRY(hipMemcpy(&n_active, next_count, 4, hipMemcpyDeviceToHost));
+    uint32_t counters[5];
+    HB_TRY(hipMemcpy(counters, st.node_count, sizeof counters, hipMemcpyDeviceToHost));
+    n_active = counters[1];
+    n_chunks = counters[3];
+    n_slots = counters[4];
+    if (n_slots > max_slots || n_chunks > max_chunks) {
+      err = "gpu bvh build: big-node bookkeeping overflow";
+      cleanup();
+      return false;
+    }
+    if (verbose && getenv("RAYCA_BUILD_LEVELS"))
+      fprintf(stderr, "[rayca build]     level %2u: %6u blocks %7.2f ms\n", level, blocks_this_level,
+              std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - lt0).count());
   }
+  lap("levels");
   uint32_t n_small = 0;
   HB_TRY(hipMemcpy(&n_small, st.small_count, 4, hipMemcpyDeviceToHost));
   if (verbose) fprintf(stderr, "[rayca build]   gpu: %u primitives, %u levels, %u node blocks, %u small subtrees\n", n, levels_run, blocks_run, n_small);
@@ -543,6 +670,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     hipLaunchKernelGGL(k_build_small, dim3((n_small + 63) / 64), dim3(64), 0, 0, st, n_small);
     HB_TRY(hipGetLastError());
   }
+  lap("small subtrees");
   uint32_t node_count = 0;
   HB_TRY(hipMemcpy(&node_count, st.node_count, 4, hipMemcpyDeviceToHost));
   std::vector<DNode> nodes(node_count);
@@ -560,7 +688,9 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     arena[i].left = nodes[i].left;
     arena[i].right = nodes[i].right;
   }
+  lap("download + convert");
   cleanup();
+  lap("free");
   return true;
 }
 

@@ -266,10 +266,12 @@ struct BlasBuilder {
 // is split, and splits happen in DFS pre-order (blas.rs:302-311).
 void to_reference_layout(const std::vector<BuildNode>& arena, std::vector<RefNode>& out) {
   out.clear();
+  out.reserve(arena.size() + 2);
   out.push_back(RefNode{arena[0].bounds.a, arena[0].bounds.b, arena[0].offset, arena[0].count});
   out.push_back(RefNode{point3(0, 0, 0), point3(0, 0, 0), 0, 0});  // slot 1 unused (blas.rs:254-256)
   struct Item { int32_t arena_idx; uint32_t ref_idx; };
   std::vector<Item> stack{{0, 0}};
+  stack.reserve(512);
   while (!stack.empty()) {
     const Item it = stack.back();
     stack.pop_back();
@@ -801,6 +803,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         soa[3][i] = p.wmin.x; soa[4][i] = p.wmin.y; soa[5][i] = p.wmin.z;
         soa[6][i] = p.wmax.x; soa[7][i] = p.wmax.y; soa[8][i] = p.wmax.z;
       }
+      lap("  host: SoA of centroids/boxes");
       BlasBuildInput in{};
       for (int c = 0; c < 3; ++c) {
         in.cent[c] = soa[c].data();
@@ -816,6 +819,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       std::vector<uint32_t> perm;
       std::vector<BlasBuildNode> dn;
       if (!g_device_builder(in, perm, dn, build_err)) return false;
+      lap("  gpu build (total)");
       std::vector<uint32_t> permuted(n);
       for (uint32_t i = 0; i < n; ++i) permuted[i] = order[perm[i]];
       order.swap(permuted);
@@ -830,7 +834,9 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     } else if (n > 0) {
       bb.split(arena, 0, 0);
     }
+    lap("  host: apply order, arena");
     to_reference_layout(arena, nodes);
+    lap("  host: reference layout");
     blas_root[m] = arena[0].bounds;
     return true;
   };
