@@ -60,7 +60,8 @@ def main():
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--builder", default="sah", choices=["sah", "reference"],
                     help="sah: SAH tree with empty-seeded candidate boxes (default); reference: the reference's tree, quirks included")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="frames rendered concurrently (frame contexts + streams)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered concurrently (frame contexts + streams); 0 = 2 on one GPU, 4 (the HIP hardware queues) with more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -108,7 +109,11 @@ def main():
     # F frames in flight: frame i renders with frame context i % F on its own stream into its own buffer, so the tail
     # of one frame (a few slow waves) overlaps the head of the next; with N > 1 the gather of a finished frame runs on
     # the comm stream meanwhile.  Every frame is still one complete pass: camera rays -> pixels (-> gather).
-    F = max(1, min(args.frames_in_flight, 4))
+    # measured on one MI355X (tests/gpu_inflight_probe.py): a whole 1080p frame per GPU is best with 2 in flight (0.497 ms
+    # against 0.656 with 1), a rank's half / quarter / eighth of it with 4 (0.262 / 0.146 / 0.094 ms); beyond 4 -- the
+    # number of HIP hardware queues -- it gets worse again
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4)
+    F = max(1, min(F, 8))
     outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
     out = outs[0]
     streams = [torch.cuda.Stream(dev) for _ in range(F)]   # render kernels, one stream per frame in flight

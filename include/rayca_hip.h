@@ -310,7 +310,7 @@ typedef struct RaycaRenderOptions {
   RaycaTile tile;         /* all zero => whole frame */
   void* stream;           /* hipStream_t to launch on, NULL => the scene's own stream */
   uint32_t engine;        /* RAYCA_ENGINE_*: which kernel family renders the frame */
-  /* Frame context 0..3.  Each context owns its work buffers and its default stream, so frames rendered with
+  /* Frame context 0..7.  Each context owns its work buffers and its default stream, so frames rendered with
    * different contexts (and different streams) may be in flight at the same time; calls that use the same
    * context are serialised.  The scene (BVH, triangles, materials) is shared. */
   uint32_t context;

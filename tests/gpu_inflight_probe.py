@@ -1,4 +1,4 @@
-"""Frames in flight: one scene handle per stream, frames dealt round-robin.  Does the tail of frame i overlap the
+"""Frames in flight: one scene, one frame context + stream per frame in flight, frames dealt round-robin.  Does the tail of frame i overlap the
 head of frame i+1?  usage: python tests/gpu_inflight_probe.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,24 +9,24 @@ W, H = 1920, 1080
 cfg = Config(max_depth=1)
 desc = flatten(scenes.atrium_scene())
 dev = torch.device("cuda", 0)
-NH = 3
-hs = [DeviceScene(desc, cfg, builder=abi.BUILDER_SAH) for _ in range(NH)]
+NH = 8
+ds = DeviceScene(desc, cfg, builder=abi.BUILDER_SAH)   # one scene, NH frame contexts
 streams = [torch.cuda.Stream(dev) for _ in range(NH)]
-for parts in (1, 8):
+for parts in (1, 2, 4, 8):
     tile = (0, parts, 8)
-    rows = hs[0].tile_rows(tile, H)
+    rows = ds.tile_rows(tile, H)
     outs = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(NH)]
-    for h, s, o in zip(hs, streams, outs):
+    for i, (s, o) in enumerate(zip(streams, outs)):
         for _ in range(8):
-            h.render_device(cfg, W, H, o.data_ptr(), 0, tile=tile, stream=s.cuda_stream, want_stats=True)
+            ds.render_device(cfg, W, H, o.data_ptr(), 0, tile=tile, stream=s.cuda_stream, want_stats=True, context=i)
     torch.cuda.synchronize()
-    for inflight in (1, 2, 3):
+    for inflight in (1, 2, 3, 4, 6, 8):
         K = 300
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(K):
             j = i % inflight
-            hs[j].render_device(cfg, W, H, outs[j].data_ptr(), 0, tile=tile, stream=streams[j].cuda_stream)
+            ds.render_device(cfg, W, H, outs[j].data_ptr(), 0, tile=tile, stream=streams[j].cuda_stream, context=j)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / K * 1e3
         print(f"parts {parts} frames in flight {inflight}: {t:.4f} ms/frame", flush=True)
