@@ -27,6 +27,9 @@ CASES = [
     ("room_ggx", Config(max_depth=3, seed=7), 160, 120),
     ("box", Config(), 200, 200),
     ("box", Config(integrator=I.Flat, samples_per_pixel=4), 64, 64),
+    ("sphere", Config(max_depth=2, seed=11), 128, 128),               # a scaled sphere (model-space hit ray, sphere.rs:138)
+    ("sphere_boxes", Config(max_depth=3, seed=12), 160, 120),
+    ("textured", Config(max_depth=2, seed=13), 128, 128),
 ]
 
 
@@ -87,3 +90,20 @@ def test_frames_in_flight_on_separate_contexts(gpu):
         assert np.array_equal(outs[i].cpu().numpy(), alone[i]), i
     with pytest.raises(Exception):
         ds.render(cfgs[0], 8, 8, context=9)
+
+
+def test_stack_machine_on_tiles_and_with_samples(gpu):
+    """The per-pixel stack machine under the multi-GPU row split and with several samples per pixel."""
+    ds, orc = G.pair("room_phong")
+    cfg = Config(integrator=I.Direct, light_samples=2, samples_per_pixel=4, gamma=2.2, seed=31)
+    w, h = 96, 75   # ragged: 75 rows in bands of 8 over 3 parts
+    _, full, _ = ds.render(cfg, w, h)
+    _, ofull, _ = orc.render(cfg, w, h)
+    assert (np.abs(full - ofull) > 1e-4 * np.maximum(1.0, np.abs(ofull))).any(-1).mean() < 0.003
+    frame = np.zeros_like(full)
+    for part in range(3):
+        _, f32, st = ds.render(cfg, w, h, tile=(part, 3, 8), collect_stats=True)
+        rows = [y for y in range(h) if (y // 8) % 3 == part]
+        assert st["rows_rendered"] == len(rows)
+        frame[rows] = f32
+    assert np.array_equal(frame.view(np.uint32), full.view(np.uint32))
