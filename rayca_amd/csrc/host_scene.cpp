@@ -12,6 +12,8 @@
 #include "host_scene.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +23,21 @@
 
 namespace rayca {
 namespace {
+
+// fn(begin, end) over [0, n) on all host threads
+template <class Fn>
+void parallel_chunks(size_t n, Fn fn) {
+  const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 4096 + 1));
+  if (nt <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t per = (n + nt - 1) / nt;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back([=, &fn] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+  fn(0, std::min(n, per));
+  for (std::thread& th : pool) th.join();
+}
 
 struct Box {
   F4 a, b;
@@ -600,6 +617,15 @@ void set_device_blas_builder(BlasBuildFn fn, uint32_t device) {
 }
 
 int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err) {
+  // RAYCA_BUILD_TIMING=1: phase times of the host build on stderr
+  static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rayca build] %-28s %8.1f ms\n", what, std::chrono::duration<float, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   if (d.abi_version != RAYCA_ABI_VERSION) { err = "abi version mismatch"; return RAYCA_ERR_BAD_ARG; }
   if (d.node_count && !d.nodes) { err = "nodes is null"; return RAYCA_ERR_BAD_ARG; }
   if (d.vertex_count && !d.positions) { err = "positions is null"; return RAYCA_ERR_BAD_ARG; }
@@ -679,6 +705,11 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   std::sort(models.begin(), models.end());
   models.erase(std::unique(models.begin(), models.end()), models.end());
 
+  struct TriJob {  // a run of triangles of one mesh primitive under one node, and where its HostPrims go
+    uint32_t node, pi, first_tri, first_out, count;
+    Mat3 tangent_matrix, normal_matrix;
+  };
+  std::vector<TriJob> jobs;
   std::vector<HostBlas> blas(models.size());
   for (size_t m = 0; m < models.size(); ++m) {
     blas[m].model = models[m];
@@ -707,33 +738,16 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           s.sphere_count++;
           continue;
         }
-        for (uint32_t t = 0; t < p.index_count / 3; ++t) {  // from_triangle_mesh_impl  primitive.rs:209-234
-          HostPrim hp{};
-          hp.kind = RAYCA_GEOMETRY_TRIANGLE_MESH;
-          hp.node = node;
-          hp.material = p.material;
-          for (int k = 0; k < 3; ++k) {
-            uint32_t idx;
-            if (!fetch_index(d, p, t * 3 + (uint32_t)k, idx)) { err = "index fetch out of range or unsupported index type"; return RAYCA_ERR_BAD_ARG; }
-            if (idx >= p.vertex_count || p.first_vertex + idx >= d.vertex_count) { err = "vertex index out of range"; return RAYCA_ERR_BAD_ARG; }
-            const uint32_t v = p.first_vertex + idx;
-            hp.p[k] = point3(d.positions[3 * v], d.positions[3 * v + 1], d.positions[3 * v + 2]);
-            const Color c = d.colors ? rgba(d.colors[4 * v], d.colors[4 * v + 1], d.colors[4 * v + 2], d.colors[4 * v + 3]) : white();
-            const F4 nrm = d.normals ? vec3(d.normals[3 * v], d.normals[3 * v + 1], d.normals[3 * v + 2]) : vec3(0, 0, 1);
-            const F4 tan = d.tangents ? vec3(d.tangents[3 * v], d.tangents[3 * v + 1], d.tangents[3 * v + 2]) : vec3(0, 0, 0);
-            const F4 bit = d.bitangents ? vec3(d.bitangents[3 * v], d.bitangents[3 * v + 1], d.bitangents[3 * v + 2]) : vec3(0, 0, 0);
-            const F2 uv = d.uvs ? F2{d.uvs[2 * v], d.uvs[2 * v + 1]} : F2{0, 0};
-            set_ext(hp.ext, k, c, mat3_apply(normal_matrix, nrm), mat3_apply(tangent_matrix, tan), mat3_apply(tangent_matrix, bit), uv);
-          }
-          hp.centroid = ((to_vec(hp.p[0]) + to_vec(hp.p[1])) + to_vec(hp.p[2])) * 0.3333f;  // triangle.rs:59-63
-          hp.ext.material = p.material;
-          hp.ext.kind = hp.kind;
-          hp.ext.node = node;
-          hp.src = (uint32_t)s.prims.size();
-          blas[m].prims.push_back(hp.src);
-          s.prims.push_back(hp);
-          s.triangle_count++;
-        }
+        // from_triangle_mesh_impl  primitive.rs:209-234: the triangles are independent -- slots are reserved
+        // here, in order, and filled by all host threads below
+        const uint32_t ntri = p.index_count / 3;
+        const uint32_t first_out = (uint32_t)s.prims.size();
+        for (uint32_t at = 0; at < ntri; at += 8192)  // pieces, so that one huge mesh still feeds every thread
+          jobs.push_back(TriJob{node, pi, at, first_out + at, std::min<uint32_t>(8192u, ntri - at), tangent_matrix, normal_matrix});
+        s.prims.resize((size_t)first_out + ntri);
+        blas[m].prims.reserve(blas[m].prims.size() + ntri);
+        for (uint32_t t = 0; t < ntri; ++t) blas[m].prims.push_back(first_out + t);
+        s.triangle_count += ntri;
       }
     }
     for (uint32_t node : light_nodes) {  // from_quad_light  primitive.rs:310-346
@@ -764,17 +778,61 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       }
     }
   }
-  for (HostPrim& p : s.prims) cache_world(p, s.world_trs[p.node]);
-  // RAYCA_BUILD_TIMING=1: phase times of the host build on stderr
-  static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
-  auto t_prev = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (!timing) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[rayca build] %-28s %8.1f ms\n", what, std::chrono::duration<float, std::milli>(now - t_prev).count());
-    t_prev = now;
-  };
-  lap("flatten + world transforms");
+  if (!jobs.empty()) {  // fill the reserved triangle slots with all host threads
+    std::atomic<int> failed{0};
+    const char* first_error = nullptr;
+    std::atomic<size_t> next_job{0};
+    auto worker = [&] {
+      for (;;) {
+        const size_t j = next_job.fetch_add(1);
+        if (j >= jobs.size() || failed.load(std::memory_order_relaxed)) return;
+        const TriJob& job = jobs[j];
+        const RaycaPrimitive& p = d.primitives[job.pi];
+        for (uint32_t t = 0; t < job.count; ++t) {
+          const uint32_t tri = job.first_tri + t;
+          HostPrim hp{};
+          hp.kind = RAYCA_GEOMETRY_TRIANGLE_MESH;
+          hp.node = job.node;
+          hp.material = p.material;
+          const char* problem = nullptr;
+          for (int k = 0; k < 3; ++k) {
+            uint32_t idx;
+            if (!fetch_index(d, p, tri * 3 + (uint32_t)k, idx)) { problem = "index fetch out of range or unsupported index type"; break; }
+            if (idx >= p.vertex_count || p.first_vertex + idx >= d.vertex_count) { problem = "vertex index out of range"; break; }
+            const uint32_t v = p.first_vertex + idx;
+            hp.p[k] = point3(d.positions[3 * v], d.positions[3 * v + 1], d.positions[3 * v + 2]);
+            const Color c = d.colors ? rgba(d.colors[4 * v], d.colors[4 * v + 1], d.colors[4 * v + 2], d.colors[4 * v + 3]) : white();
+            const F4 nrm = d.normals ? vec3(d.normals[3 * v], d.normals[3 * v + 1], d.normals[3 * v + 2]) : vec3(0, 0, 1);
+            const F4 tan = d.tangents ? vec3(d.tangents[3 * v], d.tangents[3 * v + 1], d.tangents[3 * v + 2]) : vec3(0, 0, 0);
+            const F4 bit = d.bitangents ? vec3(d.bitangents[3 * v], d.bitangents[3 * v + 1], d.bitangents[3 * v + 2]) : vec3(0, 0, 0);
+            const F2 uv = d.uvs ? F2{d.uvs[2 * v], d.uvs[2 * v + 1]} : F2{0, 0};
+            set_ext(hp.ext, k, c, mat3_apply(job.normal_matrix, nrm), mat3_apply(job.tangent_matrix, tan), mat3_apply(job.tangent_matrix, bit), uv);
+          }
+          if (problem) {
+            if (!failed.exchange(1)) first_error = problem;
+            return;
+          }
+          hp.centroid = ((to_vec(hp.p[0]) + to_vec(hp.p[1])) + to_vec(hp.p[2])) * 0.3333f;  // triangle.rs:59-63
+          hp.ext.material = p.material;
+          hp.ext.kind = hp.kind;
+          hp.ext.node = job.node;
+          hp.src = job.first_out + t;
+          s.prims[hp.src] = hp;
+        }
+      }
+    };
+    const unsigned nthreads = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)jobs.size()));
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < nthreads; ++i) pool.emplace_back(worker);
+    worker();
+    for (std::thread& th : pool) th.join();
+    if (failed.load()) { err = first_error ? first_error : "bad triangle data"; return RAYCA_ERR_BAD_ARG; }
+  }
+  lap("flatten primitives");
+  parallel_chunks(s.prims.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) cache_world(s.prims[i], s.world_trs[s.prims[i].node]);
+  });
+  lap("world-space vertices, boxes");
 
   // ---- Tlas::new: one BLAS per model ------------------------------------------------------------
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -797,12 +855,14 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       // the same recursion, level by level on the GPU (bvh_build.hip): identical tree, boxes and order
       std::vector<float> soa[9];
       for (auto& v : soa) v.resize(n);
-      for (uint32_t i = 0; i < n; ++i) {
-        const HostPrim& p = s.prims[order[i]];
-        soa[0][i] = p.wcentroid.x; soa[1][i] = p.wcentroid.y; soa[2][i] = p.wcentroid.z;
-        soa[3][i] = p.wmin.x; soa[4][i] = p.wmin.y; soa[5][i] = p.wmin.z;
-        soa[6][i] = p.wmax.x; soa[7][i] = p.wmax.y; soa[8][i] = p.wmax.z;
-      }
+      parallel_chunks(n, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          const HostPrim& p = s.prims[order[i]];
+          soa[0][i] = p.wcentroid.x; soa[1][i] = p.wcentroid.y; soa[2][i] = p.wcentroid.z;
+          soa[3][i] = p.wmin.x; soa[4][i] = p.wmin.y; soa[5][i] = p.wmin.z;
+          soa[6][i] = p.wmax.x; soa[7][i] = p.wmax.y; soa[8][i] = p.wmax.z;
+        }
+      });
       lap("  host: SoA of centroids/boxes");
       BlasBuildInput in{};
       for (int c = 0; c < 3; ++c) {
