@@ -232,8 +232,14 @@ def main():
     # passes over this same workload (profiles/pmc_traffic_<workload>.json), per launch like `achieved`
     pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
     if world == 1 and args.builder == "sah" and os.path.exists(pmc):
-        result["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
+        traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+        result["roofline"]["traffic"] = traffic
         result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
+        # `frac` prices every node and triangle a ray touches against HBM; the trees of these scenes are L2/MALL
+        # resident, so what actually crosses the HBM interface is this much smaller fraction of peak
+        result["roofline"]["traffic_frac_of_peak"] = round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        result["roofline"]["note"] = ("working set is cache resident: frac > 1 means algorithmic bytes are served by L2/MALL; the kernel is bound by "
+                                      "dependent-fetch latency (PMC: profiles/*pmc_summary.json, DESIGN.md section 8)")
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(desc, cfg, W, H, args.cpu_seconds)
     print(json.dumps(result), flush=True)
