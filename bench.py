@@ -151,7 +151,7 @@ def main():
     # the scene times binary against 4-wide nodes on its first large frames (RaycaStats.node_format bit 8) and then
     # keeps the faster: let that finish before anything is timed
     node_format = 0
-    for _ in range(12):
+    for _ in range(20):
         st0 = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
         node_format = st0["node_format"]
         if not node_format & 256:
@@ -217,7 +217,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["label"], "width": W, "height": H, "triangles": info["triangle_count"],
                    "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
-                   "node_format": {"generation0": "4-wide" if node_format & 1 else "binary", "bounces": "4-wide" if node_format & 2 else "binary", "chosen_by": "timing both on this scene"},
+                   "node_format": {"generation0": ("4-wide" if node_format & 1 else "binary") + (" fp16" if node_format & 4 else " f32"),
+                                   "bounces": ("4-wide" if node_format & 2 else "binary") + (" fp16" if node_format & 8 else " f32"),
+                                   "chosen_by": "timing the four formats on this scene (same pixels with each)"},
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",

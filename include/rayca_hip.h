@@ -336,7 +336,8 @@ typedef struct RaycaStats {
   uint32_t trace_kernel_launches;
   uint32_t rows_rendered;
   /* node format of this frame's launches: bit 0 = generation 0 used 4-wide nodes, bit 1 = the bounce
-   * generations did, bit 8 = this was a calibration frame (the scene is still timing both formats) */
+   * generations did, bits 2 / 3 = the same for fp16 node boxes, bit 8 = this was a calibration frame (the scene
+   * is still timing the formats) */
   uint32_t node_format;
 } RaycaStats;
 

@@ -48,6 +48,9 @@ struct DevLight {
 struct DevScene {
   const float4* nodes;  // 4 x float4 per DevNode (binary tree)
   const float4* nodes4; // 8 x float4 per DevNode4 (the same tree, 4-wide)
+  const uint4* nodes_h;  // 2 x uint4 per DevNodeH, 4 x uint4 per DevNode4H: the same trees with fp16 boxes (or nullptr)
+  const uint4* nodes4_h;
+  float half_center[3], half_inv_scale;
   const float* tris;    // 9 floats per primitive slot (world-space v0,v1,v2)
   const PrimExt* ext;   // per primitive slot
   const uint32_t* tie_rank;  // nullptr: ties go to the lower slot; else to the lower rank (RAYCA_BUILDER_SAH)

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <future>
 #include <chrono>
+#include <cmath>
 #include <thread>
 
 namespace rayca {
@@ -351,6 +352,35 @@ void tlas_split(std::vector<TNode>& tn, int32_t self, std::vector<uint32_t>& bla
     tn[self].right = r;
     tn[self].count = 0;
   }
+}
+
+// double -> IEEE half, rounded toward -inf (up == false) or +inf (up == true); NaN for NaN
+uint16_t to_half_directed(double v, bool up) {
+  if (v != v) return 0x7E00u;
+  const bool neg = std::signbit(v);
+  double a = std::fabs(v);
+  const bool mag_up = neg ? !up : up;  // direction on the magnitude
+  const uint16_t sign = neg ? 0x8000u : 0u;
+  if (a == 0.0) return sign;
+  if (a > 65504.0) return (uint16_t)(sign | (mag_up ? 0x7C00u : 0x7BFFu));
+  int e;
+  (void)std::frexp(a, &e);  // a = m * 2^e, m in [0.5, 1)
+  e -= 1;                    // a = m' * 2^e, m' in [1, 2)
+  if (e < -14) {             // subnormal halves: multiples of 2^-24
+    const double q = a * 16777216.0;
+    double r = mag_up ? std::ceil(q) : std::floor(q);
+    if (r >= 1024.0) return (uint16_t)(sign | 0x0400u);
+    return (uint16_t)(sign | (uint16_t)r);
+  }
+  const double unit = std::ldexp(1.0, e - 10);
+  double q = a / unit;  // in [1024, 2048)
+  double r = mag_up ? std::ceil(q) : std::floor(q);
+  if (r >= 2048.0) {
+    r = 1024.0;
+    e += 1;
+    if (e > 15) return (uint16_t)(sign | 0x7C00u);
+  }
+  return (uint16_t)(sign | ((uint16_t)(e + 15) << 10) | ((uint16_t)r - 1024u));
 }
 
 // ---- device layout -------------------------------------------------------------------------------
@@ -974,7 +1004,57 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     s.max_depth4 = need4;
     s.tie_rank.clear();
     s.ref_leaf_of.clear();
+    s.dev_nodes_h.clear();
+    s.dev_nodes4_h.clear();
     if (builder == RAYCA_BUILDER_SAH) {
+      // fp16 steering boxes: centre of the scene box, power-of-two scale that maps the half extent to <= 2^14
+      float half_extent = 0.0f;
+      const float lo3[3] = {s.root_min.x, s.root_min.y, s.root_min.z}, hi3[3] = {s.root_max.x, s.root_max.y, s.root_max.z};
+      for (int c = 0; c < 3; ++c) {
+        s.half_center[c] = 0.5f * (lo3[c] + hi3[c]);
+        if (!(s.half_center[c] == s.half_center[c]) || std::fabs(s.half_center[c]) > 1e30f) s.half_center[c] = 0.0f;
+        half_extent = std::max(half_extent, std::max(std::fabs(hi3[c] - s.half_center[c]), std::fabs(lo3[c] - s.half_center[c])));
+      }
+      int k = 0;
+      if (half_extent > 0.0f && half_extent < 1e30f) {
+        (void)std::frexp(half_extent * 1.0009765625f, &k);  // half_extent (+ padding) < 2^k
+        k = 14 - k;
+      }
+      k = std::max(-100, std::min(100, k));
+      s.half_scale = std::ldexp(1.0f, k);
+      auto cv = [&](float x, int axis, bool up) -> uint16_t {
+        if (!(x == x) || std::fabs(x) >= 1e17f) return 0x7E00u;  // "nowhere" boxes and NaNs: never entered
+        return to_half_directed(((double)x - (double)s.half_center[axis]) * (double)s.half_scale, up);
+      };
+      s.dev_nodes_h.resize(s.dev_nodes.size());
+      parallel_chunks(s.dev_nodes.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          const DevNode& n = s.dev_nodes[i];
+          DevNodeH& h = s.dev_nodes_h[i];
+          // q: l.min xyz, l.max xyz, r.min xyz, r.max xyz
+          for (int j = 0; j < 12; ++j) h.h[j] = cv(n.q[j], j % 3, (j / 3) & 1);
+          // an inverted (empty) box must stay unenterable after outward rounding
+          for (int side = 0; side < 2; ++side)
+            if (!(n.q[side * 6] <= n.q[side * 6 + 3]))
+              for (int j = 0; j < 6; ++j) h.h[side * 6 + j] = 0x7E00u;
+          h.left = n.left;
+          h.right = n.right;
+        }
+      });
+      s.dev_nodes4_h.resize(s.dev_nodes4.size());
+      parallel_chunks(s.dev_nodes4.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          const DevNode4& n = s.dev_nodes4[i];
+          DevNode4H& h = s.dev_nodes4_h[i];
+          for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c) {
+              const bool empty = !(n.lo[0][c] <= n.hi[0][c]);
+              h.lo[a][c] = empty ? 0x7E00u : cv(n.lo[a][c], a, false);
+              h.hi[a][c] = empty ? 0x7E00u : cv(n.hi[a][c], a, true);
+            }
+          for (int c = 0; c < 4; ++c) h.child[c] = n.child[c];
+        }
+      });
       s.tie_rank.resize(s.prim_order.size());
       s.ref_leaf_of.resize(s.prim_order.size());
       for (size_t slot = 0; slot < s.prim_order.size(); ++slot) {

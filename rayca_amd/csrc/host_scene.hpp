@@ -50,6 +50,20 @@ struct DevNode4 {
   uint32_t pad[4];
 };
 static_assert(sizeof(DevNode4) == 128, "DevNode4 is 128 B");
+// The same two trees with fp16 boxes (RAYCA_BUILDER_SAH only, where boxes merely steer the search): coordinates
+// are (x - half_center) * half_scale, minima rounded down and maxima up, so every box contains its f32 original.
+// 32 B and 64 B per node: half the bytes through the L1 pipe, decoded for free by v_fma_mix_f32.
+struct DevNodeH {
+  uint16_t h[12];  // l.min xyz, l.max xyz, r.min xyz, r.max xyz
+  uint32_t left, right;
+};
+static_assert(sizeof(DevNodeH) == 32, "DevNodeH is 32 B");
+struct DevNode4H {
+  uint16_t lo[3][4];
+  uint16_t hi[3][4];
+  uint32_t child[4];
+};
+static_assert(sizeof(DevNode4H) == 64, "DevNode4H is 64 B");
 constexpr uint32_t kNoChild = 0x7FFFFFFFu;
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kLeafMaxPrims = 64;
@@ -102,6 +116,10 @@ struct HostScene {
   uint32_t max_depth = 0;           // stack entries a traversal can have pending at once
   // the same tree collapsed to 4-wide nodes (every other level skipped): what the kernels traverse
   std::vector<DevNode4> dev_nodes4;
+  std::vector<DevNodeH> dev_nodes_h;     // fp16 versions (SAH builder), see DevNodeH
+  std::vector<DevNode4H> dev_nodes4_h;
+  float half_center[3] = {0, 0, 0};
+  float half_scale = 1.0f;               // a power of two
   uint32_t root_ref4 = 0;
   uint32_t max_depth4 = 0;          // pending stack entries for the 4-wide tree
   std::vector<uint32_t> tie_rank;   // RAYCA_BUILDER_SAH only: slot -> position in the reference's order

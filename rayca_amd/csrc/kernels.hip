@@ -68,9 +68,28 @@ __device__ __forceinline__ bool slab(float ax, float ay, float az, float bx, flo
 // the search and the padding of the boxes dominates its rounding error.
 struct FastRay {
   float rdx, rdy, rdz, ox, oy, oz;  // rd and -(o*rd)
+  float ax, ay, az, bx, by, bz;     // fp16 boxes: t = h * (rd / scale) + (centre - o) * rd  (unused fields cost nothing)
 };
-__device__ __forceinline__ FastRay make_fast(const DRay& r) {
-  return FastRay{r.rd.x, r.rd.y, r.rd.z, -(r.o.x * r.rd.x), -(r.o.y * r.rd.y), -(r.o.z * r.rd.z)};
+__device__ __forceinline__ FastRay make_fast(const DevScene& sc, const DRay& r) {
+  FastRay f;
+  f.rdx = r.rd.x; f.rdy = r.rd.y; f.rdz = r.rd.z;
+  f.ox = -(r.o.x * r.rd.x); f.oy = -(r.o.y * r.rd.y); f.oz = -(r.o.z * r.rd.z);
+  f.ax = r.rd.x * sc.half_inv_scale; f.ay = r.rd.y * sc.half_inv_scale; f.az = r.rd.z * sc.half_inv_scale;
+  f.bx = (sc.half_center[0] - r.o.x) * r.rd.x; f.by = (sc.half_center[1] - r.o.y) * r.rd.y; f.bz = (sc.half_center[2] - r.o.z) * r.rd.z;
+  return f;
+}
+// fp16 -> f32 is exact and free: fmaf((float)half, a, b) is one v_fma_mix_f32
+typedef _Float16 rc_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_cast(rc_h2, w).x; }
+__device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rc_h2, w).y; }
+__device__ __forceinline__ bool slab_half(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
+  const float t1x = __fmaf_rn(ax, f.ax, f.bx), t2x = __fmaf_rn(bx, f.ax, f.bx);
+  const float t1y = __fmaf_rn(ay, f.ay, f.by), t2y = __fmaf_rn(by, f.ay, f.by);
+  const float t1z = __fmaf_rn(az, f.az, f.bz), t2z = __fmaf_rn(bz, f.az, f.bz);
+  const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+  const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+  tmin_out = tmin;
+  return tmax >= tmin && tmax > 0.0f;
 }
 __device__ __forceinline__ bool slab_fast(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
   const float t1x = __fmaf_rn(ax, f.rdx, f.ox), t2x = __fmaf_rn(bx, f.rdx, f.ox);
@@ -275,9 +294,9 @@ __device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uin
 // Structure: "while-while" -- all lanes of the wave first descend inner nodes until each holds a leaf
 // (or has finished), then the leaf lanes run the triangle tests together, so the expensive leaf code
 // is not serialised against node steps of other lanes.
-template <bool ORDERED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS>
+template <bool ORDERED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS, bool HALF = false>
 __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, NodeStack<SPILL>& st, DHit& hit, LaneCounters& cnt) {
-  const FastRay fr = make_fast(r);
+  const FastRay fr = make_fast(sc, r);
   hit.t = INFINITY;
   hit.prim = RAYCA_NONE;
   hit.u = hit.v = 0.0f;
@@ -292,11 +311,28 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
   while (cur != kTerminated) {
     while (!(cur & kLeafFlag) && cur != kTerminated) {
       if (WIDE) {
+        float key[4];
+        uint32_t ref[4];
+        if (FAST && HALF) {
+          const uint4* np = sc.nodes4_h + 4ull * cur;
+          const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+          if (STATS) cnt.boxes += 4;
+          ref[0] = q3.x; ref[1] = q3.y; ref[2] = q3.z; ref[3] = q3.w;
+          const float ax[4] = {lo16(q0.x), hi16(q0.x), lo16(q0.y), hi16(q0.y)}, ay[4] = {lo16(q0.z), hi16(q0.z), lo16(q0.w), hi16(q0.w)};
+          const float az[4] = {lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y)}, bx[4] = {lo16(q1.z), hi16(q1.z), lo16(q1.w), hi16(q1.w)};
+          const float by[4] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y)}, bz[4] = {lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float tc;
+            bool h = slab_half(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc);
+            if (ORDERED) h = h && tc <= limit;
+            key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
+          }
+        } else {
         const float4* np = sc.nodes4 + 8ull * cur;
         const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
         if (STATS) cnt.boxes += 4;
-        float key[4];
-        uint32_t ref[4] = {__float_as_uint(cr.x), __float_as_uint(cr.y), __float_as_uint(cr.z), __float_as_uint(cr.w)};
+        ref[0] = __float_as_uint(cr.x); ref[1] = __float_as_uint(cr.y); ref[2] = __float_as_uint(cr.z); ref[3] = __float_as_uint(cr.w);
         const float ax[4] = {lx.x, lx.y, lx.z, lx.w}, ay[4] = {ly.x, ly.y, ly.z, ly.w}, az[4] = {lz.x, lz.y, lz.z, lz.w};
         const float bx[4] = {hx.x, hx.y, hx.z, hx.w}, by[4] = {hy.x, hy.y, hy.z, hy.w}, bz[4] = {hz.x, hz.y, hz.z, hz.w};
 #pragma unroll
@@ -306,6 +342,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
           if (ORDERED) h = h && tc <= limit;
           // sort key: entry distance (ORDERED) or the child's index (reference order); misses sort last
           key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
+        }
         }
         // 5-comparator network, strict `>` so equal keys keep their index order (the chains that
         // split big leaves rely on it: see WideBuilder)
@@ -326,19 +363,30 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
         if (key[1] < INFINITY) st.push(ref[1]);
         cur = key[0] < INFINITY ? ref[0] : st.pop();
       } else {
-        const float4* np = sc.nodes + 4ull * cur;
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
         float tl, tr;
         bool hl, hr;
-        if (FAST) {
-          hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
-          hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
+        uint32_t lref, rref;
+        if (FAST && HALF) {
+          const uint4* nh = sc.nodes_h + 2ull * cur;
+          const uint4 a = nh[0], b = nh[1];
+          hl = slab_half(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), fr, tl);
+          hr = slab_half(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), fr, tr);
+          lref = b.z;
+          rref = b.w;
         } else {
-          hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
-          hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+          const float4* np = sc.nodes + 4ull * cur;
+          const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+          if (FAST) {
+            hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
+            hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
+          } else {
+            hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
+            hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+          }
+          lref = __float_as_uint(q3.x);
+          rref = __float_as_uint(q3.y);
         }
         if (STATS) cnt.boxes += 2;
-        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
         if (ORDERED) {
           hl = hl && tl <= limit;
           hr = hr && tr <= limit;
@@ -714,7 +762,7 @@ __device__ __forceinline__ NeeSample nee_prepare(const DevScene& sc, const Frame
 //   primary ray -> shade -> [NEE shadow ray]* -> bounce sample -> done
 // so the traversal loop is instantiated once per kernel and the registers that must survive it are
 // the ray, the hit, the compact ShadeCtx and a few colours.
-template <int MODE, bool GEN0, bool ORDERED, bool FUSED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS>
+template <int MODE, bool GEN0, bool ORDERED, bool FUSED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS, bool HALF>
 __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : RAYCA_MIN_WAVES) void k_generation(DevScene sc, FrameParams fp, uint32_t* heads, const QueuedRay* in_rays,
                                                        const uint32_t* in_count, QueuedRay* out_rays, uint32_t* out_count,
                                                        PathBuffers pb, uint32_t depth, uint8_t* rgba8, float4* rgba32f,
@@ -776,7 +824,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
     while (live) {
       DHit hit;
       const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
-      const bool found = trace<ORDERED, FAST, SPH, WIDE, SPILL, STATS>(sc, ray, t_stop, stack, hit, cnt);
+      const bool found = trace<ORDERED, FAST, SPH, WIDE, SPILL, STATS, HALF>(sc, ray, t_stop, stack, hit, cnt);
       if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
         uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
         for (int off = 32; off > 0; off >>= 1) {

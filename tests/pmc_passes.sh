@@ -4,7 +4,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 # counter collection perturbs the scene's own timing of binary vs 4-wide nodes: pin the format bench.py chose
 # for these workloads (config.node_format in the bench line)
-export RAYCA_WIDE=${RAYCA_WIDE:-1}
+export RAYCA_NODE_FORMAT=${RAYCA_NODE_FORMAT:-1}
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SALU TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"; do
   i=$((i+1))
