@@ -360,6 +360,9 @@ typedef struct RaycaScene RaycaScene; /* opaque: owns the device-resident scene 
 uint32_t rayca_hip_version(void);
 /* number of visible HIP devices; 0 (not an error) when there is none */
 int32_t rayca_hip_device_count(void);
+/* Host-side self-checks that need no GPU (currently: the outward fp16 rounding of the steering boxes, exhaustive
+ * over all finite halves).  RAYCA_OK or an error with a message in rayca_hip_last_error. */
+int32_t rayca_hip_selftest(void);
 /* copies the calling thread's last error message (NUL terminated) */
 void rayca_hip_last_error(char* buf, size_t len);
 

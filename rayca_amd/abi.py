@@ -321,6 +321,8 @@ def bind_product_signatures(lib):
     lib.rayca_hip_version.argtypes = []
     lib.rayca_hip_device_count.restype = C.c_int32
     lib.rayca_hip_device_count.argtypes = []
+    lib.rayca_hip_selftest.restype = C.c_int32
+    lib.rayca_hip_selftest.argtypes = []
     lib.rayca_hip_last_error.restype = None
     lib.rayca_hip_last_error.argtypes = [C.c_char_p, C.c_size_t]
     lib.rayca_hip_config_default.restype = None
@@ -348,7 +350,7 @@ def bind_product_signatures(lib):
 
 
 PRODUCT_SYMBOLS = [
-    "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_last_error", "rayca_hip_config_default",
+    "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_selftest", "rayca_hip_last_error", "rayca_hip_config_default",
     "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_info", "rayca_hip_render",
     "rayca_hip_render_device", "rayca_hip_tile_rows", "rayca_hip_trace_rays",
     "rayca_hip_scene_primitive_order",

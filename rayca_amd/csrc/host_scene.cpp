@@ -641,6 +641,41 @@ void set_ext(PrimExt& e, int k, Color c, F4 n, F4 t, F4 b, F2 uv) {
 
 }  // namespace
 
+// Self-check of the outward fp16 rounding the steering boxes rely on: every finite half maps to itself in both
+// directions, and for values between two neighbouring halves `down` and `up` return exactly those neighbours.
+int32_t selftest_half_rounding(std::string& err) {
+  auto decode = [](uint16_t h) -> double {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp(1024.0 + m, e - 25);
+    return (h & 0x8000u) ? -v : v;
+  };
+  auto fail = [&](const char* what, double v) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "half rounding: %s at %.17g", what, v);
+    err = buf;
+    return (int32_t)RAYCA_ERR_BAD_ARG;
+  };
+  for (uint32_t h = 0; h < 65536u; ++h) {
+    if (((h >> 10) & 31u) == 31u) continue;  // inf / NaN
+    const double v = decode((uint16_t)h);
+    if (decode(to_half_directed(v, false)) != v || decode(to_half_directed(v, true)) != v) return fail("exact value moved", v);
+    // the next half above (same sign ordering on the real line)
+    const uint16_t up_bits = (h & 0x8000u) ? (uint16_t)((h & 0x7FFFu) == 0 ? 0x0001u : h - 1u) : (uint16_t)(h + 1u);
+    if (((up_bits >> 10) & 31u) == 31u) continue;
+    const double w = decode(up_bits);
+    if (!(w > v)) continue;  // -0 / +0
+    for (const double f : {0.25, 0.5, 0.999}) {
+      const double x = v + (w - v) * f;
+      const double lo = decode(to_half_directed(x, false)), hi = decode(to_half_directed(x, true));
+      if (lo != v || hi != w) return fail("bracket is not the two neighbours", x);
+    }
+  }
+  if (to_half_directed(1e6, true) != 0x7C00u || to_half_directed(1e6, false) != 0x7BFFu) return fail("overflow", 1e6);
+  if (to_half_directed(-1e6, false) != 0xFC00u || to_half_directed(-1e6, true) != 0xFBFFu) return fail("overflow", -1e6);
+  if (to_half_directed(1e-9, true) != 0x0001u || to_half_directed(1e-9, false) != 0x0000u) return fail("underflow", 1e-9);
+  return RAYCA_OK;
+}
+
 void set_device_blas_builder(BlasBuildFn fn, uint32_t device) {
   g_device_builder = fn;
   g_device_ordinal = device;

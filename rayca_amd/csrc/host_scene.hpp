@@ -152,6 +152,7 @@ struct BlasBuildNode {
 };
 using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
 void set_device_blas_builder(BlasBuildFn fn, uint32_t device);
+int32_t selftest_half_rounding(std::string& err);
 bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
 
 }  // namespace rayca

@@ -87,3 +87,10 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"oracle", txt, re.I):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_host_selftest_fp16_outward_rounding(product_lib):
+    """The fp16 steering boxes must contain their f32 originals: the directed rounding is checked exhaustively over
+    all finite halves inside the library (host code, no GPU)."""
+    from rayca_amd import lib
+    lib.check(product_lib.rayca_hip_selftest())
