@@ -448,3 +448,25 @@ def test_gpu_builder_builds_the_host_builders_tree(gpu, name):
         assert_exact(fa, fb)
         a.close()
         b.close()
+
+
+def test_gpu_builder_with_several_large_models(gpu):
+    """Two BLASes above the GPU-builder threshold under one TLAS (plus the default model): device build == host build,
+    and both match the oracle bit for bit on a Flat frame."""
+    scene = scenes.soup_scene(6000, seed=0xA11CE, extent=0.08)
+    other = scenes.soup_scene(5000, seed=0xB0B, extent=0.06)
+    n = scene.push_model(other.models[0])
+    scene.nodes[n].trs = Trs(translation=(0.4, -0.2, 0.3), scale=(0.7, 0.7, 0.7))
+    desc = flatten(scene)
+    orc = ol.OracleScene(desc, Config())
+    _, of32, _ = orc.render(FLAT, 160, 120)
+    for builder in (abi.BUILDER_REFERENCE, abi.BUILDER_SAH):
+        a = DeviceScene(desc, Config(), builder=builder)
+        b = DeviceScene(desc, Config(), builder=builder, build_on_host=True)
+        assert a.info()["blas_count"] == 2 and a.info()["node_count"] == b.info()["node_count"]
+        assert np.array_equal(a.primitive_order(), b.primitive_order())
+        _, fa, _ = a.render(FLAT, 160, 120)
+        _, fb, _ = b.render(FLAT, 160, 120)
+        assert_exact(fa, fb)
+        assert_exact(fa, of32)
+        assert (fa[..., :3].sum(-1) > 0).sum() > 500
