@@ -112,6 +112,7 @@ def main():
     # measured on one MI355X (tests/gpu_inflight_probe.py): a whole 1080p frame per GPU is best with 2 in flight (0.497 ms
     # against 0.656 with 1), a rank's half / quarter / eighth of it with 4 (0.262 / 0.146 / 0.094 ms); beyond 4 -- the
     # number of HIP hardware queues -- it gets worse again
+    wl_generations = int(getattr(cfg, "max_depth", 1)) if int(getattr(cfg, "integrator", 5)) == 5 else 1
     F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4)
     F = max(1, min(F, 8))
     outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
@@ -224,7 +225,7 @@ def main():
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
                    "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "none")},
-        "roofline": {"bound": "hbm", "kernel": "k_generation (generation 0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from four generations up)" if wl_generations >= 4 else "k_generation (generation 0)"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4),
                      "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),
