@@ -325,9 +325,10 @@ typedef struct RaycaStats {
   uint64_t boxes_tested;     /* only with collect_stats: AABB slab tests (32 B each)            */
   uint64_t triangles_tested; /* only with collect_stats: ray/triangle tests (36 B each)         */
   uint64_t hits_shaded;      /* only with collect_stats */
-  /* only with collect_stats: SIMD-slot accounting of the traversal.  For every 64-ray batch the
-   * kernel adds 64 x (the largest per-lane box-test / triangle-test count in the wave): what a
-   * lock-step wave pays.  boxes_tested / wave_box_slots is the lane utilisation of the node loop. */
+  /* only with collect_stats: SIMD-slot accounting of the traversal.  Every trip a wave
+   * takes through the node loop books 64 x (boxes per node) slots, every trip through the leaf loop 64
+   * slots, whatever the number of lanes still taking part: what the lock-step wave pays.
+   * boxes_tested / wave_box_slots is the lane utilisation of the node loop. */
   uint64_t wave_box_slots;
   uint64_t wave_triangle_slots;
   float kernel_ms;           /* HIP-event time over all kernels of the frame, on the launch stream */

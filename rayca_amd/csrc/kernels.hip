@@ -211,6 +211,10 @@ __device__ __forceinline__ bool reference_candidate(const DevScene& sc, uint32_t
 
 struct LaneCounters {
   uint32_t boxes = 0, tris = 0;
+  // STATS only: what the lock-step wave pays -- every trip of the node loop / the leaf loop costs all 64 lanes,
+  // booked by the first lane that takes the trip
+  unsigned long long slot_boxes = 0, slot_tris = 0;
+  __device__ __forceinline__ bool books() const { return __lane_id() == (uint32_t)__ffsll((long long)__ballot(1)) - 1u; }
 };
 
 constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index that never exists (== kNoChild)
@@ -255,7 +259,10 @@ __device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uin
   for (uint32_t i = first; i < first + count; ++i) {
     F4 v0, v1, v2;
     load_tri(sc, i, v0, v1, v2);
-    if (STATS) cnt.tris++;
+    if (STATS) {
+      cnt.tris++;
+      if (cnt.books()) cnt.slot_tris += 64ull;
+    }
     float t, u, v;
     bool got;
     if (SPH && v0.x != v0.x) {  // sphere slot
@@ -277,6 +284,108 @@ __device__ __forceinline__ void test_leaf(const DevScene& sc, const DRay& r, uin
       }
     }
   }
+}
+
+// One trip through the node loop: test the children of inner node `cur`, push what stays pending, return the
+// next node (inner, leaf or kTerminated).
+template <bool ORDERED, bool FAST, bool WIDE, bool SPILL, bool STATS, bool HALF>
+__device__ __forceinline__ uint32_t node_step(const DevScene& sc, const DRay& r, const FastRay& fr, float limit, uint32_t cur, NodeStack<SPILL>& st,
+                                              LaneCounters& cnt) {
+  if (STATS && cnt.books()) cnt.slot_boxes += WIDE ? 256ull : 128ull;
+  if (WIDE) {
+    float key[4];
+    uint32_t ref[4];
+    if (FAST && HALF) {
+      const uint4* np = sc.nodes4_h + 4ull * cur;
+      const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+      if (STATS) cnt.boxes += 4;
+      ref[0] = q3.x; ref[1] = q3.y; ref[2] = q3.z; ref[3] = q3.w;
+      const float ax[4] = {lo16(q0.x), hi16(q0.x), lo16(q0.y), hi16(q0.y)}, ay[4] = {lo16(q0.z), hi16(q0.z), lo16(q0.w), hi16(q0.w)};
+      const float az[4] = {lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y)}, bx[4] = {lo16(q1.z), hi16(q1.z), lo16(q1.w), hi16(q1.w)};
+      const float by[4] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y)}, bz[4] = {lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float tc;
+        bool h = slab_half(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc);
+        if (ORDERED) h = h && tc <= limit;
+        key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
+      }
+    } else {
+    const float4* np = sc.nodes4 + 8ull * cur;
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
+    if (STATS) cnt.boxes += 4;
+    ref[0] = __float_as_uint(cr.x); ref[1] = __float_as_uint(cr.y); ref[2] = __float_as_uint(cr.z); ref[3] = __float_as_uint(cr.w);
+    const float ax[4] = {lx.x, lx.y, lx.z, lx.w}, ay[4] = {ly.x, ly.y, ly.z, ly.w}, az[4] = {lz.x, lz.y, lz.z, lz.w};
+    const float bx[4] = {hx.x, hx.y, hx.z, hx.w}, by[4] = {hy.x, hy.y, hy.z, hy.w}, bz[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float tc;
+      bool h = FAST ? slab_fast(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc) : slab(ax[c], ay[c], az[c], bx[c], by[c], bz[c], r, tc);
+      if (ORDERED) h = h && tc <= limit;
+      // sort key: entry distance (ORDERED) or the child's index (reference order); misses sort last
+      key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
+    }
+    }
+    // 5-comparator network, strict `>` so equal keys keep their index order (the chains that
+    // split big leaves rely on it: see WideBuilder)
+#define RC_CE(i, j)                                  \
+  {                                                  \
+const bool sw = key[i] > key[j];                 \
+const float ka = sw ? key[j] : key[i];           \
+const float kb = sw ? key[i] : key[j];           \
+const uint32_t ra = sw ? ref[j] : ref[i];        \
+const uint32_t rb = sw ? ref[i] : ref[j];        \
+key[i] = ka; key[j] = kb; ref[i] = ra; ref[j] = rb; \
+  }
+    RC_CE(0, 1) RC_CE(2, 3) RC_CE(0, 2) RC_CE(1, 3) RC_CE(1, 2)
+#undef RC_CE
+    // farthest first, so the nearest pending sibling is popped first
+    if (key[3] < INFINITY) st.push(ref[3]);
+    if (key[2] < INFINITY) st.push(ref[2]);
+    if (key[1] < INFINITY) st.push(ref[1]);
+    cur = key[0] < INFINITY ? ref[0] : st.pop();
+  } else {
+    float tl, tr;
+    bool hl, hr;
+    uint32_t lref, rref;
+    if (FAST && HALF) {
+      const uint4* nh = sc.nodes_h + 2ull * cur;
+      const uint4 a = nh[0], b = nh[1];
+      hl = slab_half(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), fr, tl);
+      hr = slab_half(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), fr, tr);
+      lref = b.z;
+      rref = b.w;
+    } else {
+      const float4* np = sc.nodes + 4ull * cur;
+      const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+      if (FAST) {
+        hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
+        hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
+      } else {
+        hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
+        hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
+      }
+      lref = __float_as_uint(q3.x);
+      rref = __float_as_uint(q3.y);
+    }
+    if (STATS) cnt.boxes += 2;
+    if (ORDERED) {
+      hl = hl && tl <= limit;
+      hr = hr && tr <= limit;
+    }
+    if (hl && hr) {
+      const bool left_first = !ORDERED || tl <= tr;
+      st.push(left_first ? rref : lref);
+      cur = left_first ? lref : rref;
+    } else if (hl) {
+      cur = lref;
+    } else if (hr) {
+      cur = rref;
+    } else {
+      cur = st.pop();
+    }
+  }
+  return cur;
 }
 
 // Closest hit along `r` (Tlas::intersects).
@@ -310,99 +419,7 @@ __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t
   if (any_hit) limit = t_stop + fabsf(t_stop) * 9.765625e-4f + sc.cull_abs;
   while (cur != kTerminated) {
     while (!(cur & kLeafFlag) && cur != kTerminated) {
-      if (WIDE) {
-        float key[4];
-        uint32_t ref[4];
-        if (FAST && HALF) {
-          const uint4* np = sc.nodes4_h + 4ull * cur;
-          const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-          if (STATS) cnt.boxes += 4;
-          ref[0] = q3.x; ref[1] = q3.y; ref[2] = q3.z; ref[3] = q3.w;
-          const float ax[4] = {lo16(q0.x), hi16(q0.x), lo16(q0.y), hi16(q0.y)}, ay[4] = {lo16(q0.z), hi16(q0.z), lo16(q0.w), hi16(q0.w)};
-          const float az[4] = {lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y)}, bx[4] = {lo16(q1.z), hi16(q1.z), lo16(q1.w), hi16(q1.w)};
-          const float by[4] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y)}, bz[4] = {lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            float tc;
-            bool h = slab_half(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc);
-            if (ORDERED) h = h && tc <= limit;
-            key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
-          }
-        } else {
-        const float4* np = sc.nodes4 + 8ull * cur;
-        const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cr = np[6];
-        if (STATS) cnt.boxes += 4;
-        ref[0] = __float_as_uint(cr.x); ref[1] = __float_as_uint(cr.y); ref[2] = __float_as_uint(cr.z); ref[3] = __float_as_uint(cr.w);
-        const float ax[4] = {lx.x, lx.y, lx.z, lx.w}, ay[4] = {ly.x, ly.y, ly.z, ly.w}, az[4] = {lz.x, lz.y, lz.z, lz.w};
-        const float bx[4] = {hx.x, hx.y, hx.z, hx.w}, by[4] = {hy.x, hy.y, hy.z, hy.w}, bz[4] = {hz.x, hz.y, hz.z, hz.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float tc;
-          bool h = FAST ? slab_fast(ax[c], ay[c], az[c], bx[c], by[c], bz[c], fr, tc) : slab(ax[c], ay[c], az[c], bx[c], by[c], bz[c], r, tc);
-          if (ORDERED) h = h && tc <= limit;
-          // sort key: entry distance (ORDERED) or the child's index (reference order); misses sort last
-          key[c] = h ? (ORDERED ? tc : (float)c) : INFINITY;
-        }
-        }
-        // 5-comparator network, strict `>` so equal keys keep their index order (the chains that
-        // split big leaves rely on it: see WideBuilder)
-#define RC_CE(i, j)                                  \
-  {                                                  \
-    const bool sw = key[i] > key[j];                 \
-    const float ka = sw ? key[j] : key[i];           \
-    const float kb = sw ? key[i] : key[j];           \
-    const uint32_t ra = sw ? ref[j] : ref[i];        \
-    const uint32_t rb = sw ? ref[i] : ref[j];        \
-    key[i] = ka; key[j] = kb; ref[i] = ra; ref[j] = rb; \
-  }
-        RC_CE(0, 1) RC_CE(2, 3) RC_CE(0, 2) RC_CE(1, 3) RC_CE(1, 2)
-#undef RC_CE
-        // farthest first, so the nearest pending sibling is popped first
-        if (key[3] < INFINITY) st.push(ref[3]);
-        if (key[2] < INFINITY) st.push(ref[2]);
-        if (key[1] < INFINITY) st.push(ref[1]);
-        cur = key[0] < INFINITY ? ref[0] : st.pop();
-      } else {
-        float tl, tr;
-        bool hl, hr;
-        uint32_t lref, rref;
-        if (FAST && HALF) {
-          const uint4* nh = sc.nodes_h + 2ull * cur;
-          const uint4 a = nh[0], b = nh[1];
-          hl = slab_half(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), fr, tl);
-          hr = slab_half(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), fr, tr);
-          lref = b.z;
-          rref = b.w;
-        } else {
-          const float4* np = sc.nodes + 4ull * cur;
-          const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-          if (FAST) {
-            hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, fr, tl);
-            hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, fr, tr);
-          } else {
-            hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, tl);
-            hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, tr);
-          }
-          lref = __float_as_uint(q3.x);
-          rref = __float_as_uint(q3.y);
-        }
-        if (STATS) cnt.boxes += 2;
-        if (ORDERED) {
-          hl = hl && tl <= limit;
-          hr = hr && tr <= limit;
-        }
-        if (hl && hr) {
-          const bool left_first = !ORDERED || tl <= tr;
-          st.push(left_first ? rref : lref);
-          cur = left_first ? lref : rref;
-        } else if (hl) {
-          cur = lref;
-        } else if (hr) {
-          cur = rref;
-        } else {
-          cur = st.pop();
-        }
-      }
+      cur = node_step<ORDERED, FAST, WIDE, SPILL, STATS, HALF>(sc, r, fr, limit, cur, st, cnt);
     }
     if (cur != kTerminated) {  // a leaf
       test_leaf<ORDERED, SPH, STATS>(sc, r, cur, t_stop, hit, limit, cnt);
@@ -775,7 +792,6 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
   const uint32_t total = GEN0 ? fp.tile_count : (*in_count + 63u) / 64u;
   LaneCounters cnt;
   uint32_t n_shaded = 0, n_shadow = 0, n_bounce = 0;
-  unsigned long long slot_boxes = 0, slot_tris = 0;
   const bool collect_emissive = GEN0 ? true : (fp.direct_sampler == RAYCA_SAMPLER_NONE);
   const uint32_t nee_lights = (MODE == kModePath && fp.direct_sampler == RAYCA_SAMPLER_NEE) ? sc.light_count : 0u;
 
@@ -823,22 +839,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
 
     while (live) {
       DHit hit;
-      const uint32_t boxes_before = cnt.boxes, tris_before = cnt.tris;
       const bool found = trace<ORDERED, FAST, SPH, WIDE, SPILL, STATS, HALF>(sc, ray, t_stop, stack, hit, cnt);
-      if (STATS) {  // what a lock-step wave pays for this traversal: 64 x the busiest lane
-        uint32_t db = cnt.boxes - boxes_before, dt = cnt.tris - tris_before;
-        for (int off = 32; off > 0; off >>= 1) {
-          db = max(db, (uint32_t)__shfl_xor((int)db, off));
-          dt = max(dt, (uint32_t)__shfl_xor((int)dt, off));
-        }
-        // lanes that are not live did not take part: the maxima over the active lanes are what counts,
-        // and every active lane holds them now; the first active lane books them
-        const unsigned long long act = __ballot(1);
-        if (lane == (uint32_t)__ffsll((long long)act) - 1u) {
-          slot_boxes += 64ull * db;
-          slot_tris += 64ull * dt;
-        }
-      }
       if (!in_shadow) {
         if (!found) {
           if (FUSED) direct = black() + black();  // unwrap_or(BLACK), color += it
@@ -936,7 +937,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
   }
   if (STATS) {
     // wave reduction, then one atomic per wave and counter
-    unsigned long long b = cnt.boxes, t = cnt.tris, sh = n_shaded, sb = slot_boxes, stt = slot_tris;
+    unsigned long long b = cnt.boxes, t = cnt.tris, sh = n_shaded, sb = cnt.slot_boxes, stt = cnt.slot_tris;
     for (int off = 32; off > 0; off >>= 1) {
       b += __shfl_down(b, off);
       t += __shfl_down(t, off);
