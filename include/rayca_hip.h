@@ -277,8 +277,8 @@ enum {
   /* always the per-pixel stack machine (k_general): every IntegratorStrategy / SamplerStrategy the
    * reference has.  Same results as AUTO where both apply (tested); slower. */
   RAYCA_ENGINE_GENERAL = 1,
-  /* the generation kernels' frames with traversal split from shading: lean trace kernels with lane-level
-   * refill + a streaming shade kernel per generation (wavefront.inc).  Same Configs as the generation
+  /* the generation kernels' frames with traversal split from shading: lean one-thread-per-ray trace
+   * kernels + a streaming shade kernel per generation (wavefront.inc).  Same Configs as the generation
    * kernels, same bits (tested). */
   RAYCA_ENGINE_WAVEFRONT = 2,
   /* the fused persistent kernel per generation (k_generation) */

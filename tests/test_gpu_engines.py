@@ -1,5 +1,5 @@
 """The two generation-by-generation engines -- the fused persistent kernel (k_generation) and the wavefront split
-(lean trace kernels with lane-level refill + streaming shade kernel, wavefront.inc) -- must produce the same bits:
+(lean one-thread-per-ray trace kernels + streaming shade kernel, wavefront.inc) -- must produce the same bits:
 they share every arithmetic routine and differ only in scheduling."""
 import numpy as np
 import pytest
@@ -43,6 +43,12 @@ def test_engines_agree(gpu, case):
     for k in ("rays_primary", "rays_shadow", "rays_bounce", "hits_shaded"):
         assert sa[k] == sb[k], k
     assert float(fa[..., :3].max()) > 0.0
+    # SIMD-slot accounting (include/rayca_hip.h): a wave books 64 lanes per trip through the node / leaf loop, so the
+    # slots bound the per-lane tests from above (the root box of every ray is tested outside the node loop)
+    rays = sa["rays_primary"] + sa["rays_shadow"] + sa["rays_bounce"]
+    for st in (sa, sb):
+        assert st["wave_box_slots"] >= st["boxes_tested"] - rays > 0
+        assert st["wave_triangle_slots"] >= st["triangles_tested"] > 0
 
 
 def test_engines_agree_on_tiles_and_builders(gpu):
