@@ -62,6 +62,8 @@ def main():
                     help="sah: SAH tree with empty-seeded candidate boxes (default); reference: the reference's tree, quirks included")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently (frame contexts + streams); 0 = 2 on one GPU, 4 (the HIP hardware queues) with more")
+    ap.add_argument("--gather-batch", type=int, default=4,
+                    help="N > 1: finished frames gathered per collective (1 = one gather per frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -120,34 +122,55 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(F)]   # render kernels, one stream per frame in flight
     stream = streams[0]
     comm = torch.cuda.Stream(dev)                           # frame gather (RCCL)
-    ev_render = [torch.cuda.Event() for _ in range(F)]
-    ev_gather = [torch.cuda.Event() for _ in range(F)]
-    for e in ev_gather:
-        e.record(comm)
     counter = [0]
     gather_dev = dev if backend == "nccl" else torch.device("cpu")
-    gatherer = FrameGatherer(H, W, args.band_rows, gather_dev) if world > 1 else None
-    frames = [torch.empty((H, W, 4), dtype=torch.uint8, device=gather_dev) for _ in range(F)] if (world > 1 and rank == 0) else [None] * F
+    # N > 1: finished frames are gathered B at a time with ONE collective (a rank's rows of a 1080p frame are 1 MB at
+    # 8 ranks: per-call latency and the all-rank synchronisation of a collective cost more than its bytes).  Frames are
+    # rendered straight into slot b of one of two batch buffers; the gather of a batch overlaps the next batch's rendering.
+    B = max(1, min(args.gather_batch, 8)) if world > 1 else 1
+    gatherer = FrameGatherer(H, W, args.band_rows, gather_dev, batch=B) if world > 1 else None
+    sends = [torch.zeros((B, gatherer.max_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else []
+    frames = [torch.empty((B, H, W, 4), dtype=torch.uint8, device=gather_dev) for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
+    ev_render = [[torch.cuda.Event() for _ in range(B)] for _ in range(2)]
+    ev_gather = [torch.cuda.Event() for _ in range(2)]
+    for e in ev_gather:
+        e.record(comm)
 
-    def step(want_stats=False):
-        i = counter[0] % F
-        counter[0] += 1
-        buf, st_i = outs[i], streams[i]
-        with torch.cuda.stream(st_i):
-            st_i.wait_event(ev_gather[i])   # the previous gather out of this buffer has finished
-            st = ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_i.cuda_stream, want_stats=want_stats, context=i)
-            ev_render[i].record(st_i)
-        if world == 1:
-            return st, buf
+    def flush(k, n):
+        """gather the first n frames' worth of batch buffer k (always the whole buffer: one message shape)"""
         with torch.cuda.stream(comm):
-            comm.wait_event(ev_render[i])
+            for e in ev_render[k][:n]:
+                comm.wait_event(e)
             if backend == "nccl":
-                frame = gatherer(buf, frames[i])
+                got = gatherer.gather_batch(sends[k], frames[k])
             else:  # rehearsal: gloo gathers host tensors
                 comm.synchronize()
-                frame = gatherer(buf.cpu(), frames[i])
-            ev_gather[i].record(comm)
-        return st, frame
+                got = gatherer.gather_batch(sends[k].cpu(), frames[k])
+            ev_gather[k].record(comm)
+        return got
+
+    def step(want_stats=False):
+        i = counter[0]
+        counter[0] += 1
+        c = i % F
+        st_c = streams[c]
+        if world == 1:
+            with torch.cuda.stream(st_c):
+                st = ds.render_device(cfg, W, H, outs[c].data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, want_stats=want_stats, context=c)
+            return st, outs[c]
+        b, k = i % B, (i // B) % 2
+        buf = sends[k][b, :my_rows]
+        with torch.cuda.stream(st_c):
+            st_c.wait_event(ev_gather[k])   # the previous gather out of this batch buffer has finished
+            st = ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, want_stats=want_stats, context=c)
+            ev_render[k][b].record(st_c)
+        return st, (flush(k, B) if b == B - 1 else None)
+
+    def drain():
+        """gather what an incomplete batch holds and start the next step on a batch boundary"""
+        if world > 1 and counter[0] % B:
+            flush((counter[0] // B) % 2, counter[0] % B)
+        counter[0] = 0
 
     # the scene times binary against 4-wide nodes on its first large frames (RaycaStats.node_format bit 8) and then
     # keeps the faster: let that finish before anything is timed
@@ -167,12 +190,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, frame = step()
+    drain()   # every one of the K frames is gathered inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,7 +249,8 @@ def main():
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
-                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else "none")},
+                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, {B} finished frame(s) per collective, overlapped with rendering"
+                                    if world > 1 else "none")},
         "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from four generations up)" if wl_generations >= 4 else "k_generation (generation 0)"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4),

@@ -36,11 +36,27 @@ def _worker(rank, world, port, height, width, band, out_path):
     u8, _, st = orc.render(cfg, width, height, tile=tile, want_f32=False)
     assert st["rows_rendered"] == rows_of(tile, height).numel() == u8.shape[0]
     frame = gather_frame(torch.from_numpy(u8), height, band)
+    # the batched form bench.py uses for N > 1: three frames (the frame, its complement, zeros) in one collective
+    from rayca_amd.distributed import FrameGatherer
+    g3 = FrameGatherer(height, width, band, "cpu", batch=3)
+    send = g3.new_send()
+    send[0, : g3.my_rows] = torch.from_numpy(u8)
+    send[1, : g3.my_rows] = 255 - torch.from_numpy(u8)
+    batch = g3.gather_batch(send)
+    g1 = FrameGatherer(height, width, band, "cpu", batch=1)   # --gather-batch 1: the same call shape, one frame
+    send1 = g1.new_send()
+    send1[0, : g1.my_rows] = torch.from_numpy(u8)
+    one = g1.gather_batch(send1)
+    assert (one is None) == (rank != 0)
     if rank == 0:
         full, _, _ = orc.render(cfg, width, height, want_f32=False)
+        assert np.array_equal(one[0].numpy(), frame.numpy())
+        assert np.array_equal(batch[0].numpy(), frame.numpy())
+        assert np.array_equal(batch[1].numpy(), 255 - frame.numpy())
+        assert int(batch[2].sum()) == 0
         np.save(out_path, np.stack([frame.numpy(), full]))
     else:
-        assert frame is None
+        assert frame is None and batch is None
     dist.barrier()
     dist.destroy_process_group()
 
