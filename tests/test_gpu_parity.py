@@ -411,6 +411,36 @@ def test_spheres(gpu, with_boxes):
             assert np.array_equal(prim, oprim) and np.array_equal(bits(t), bits(ot))
 
 
+def test_config3_soup_4096_full_size(gpu):
+    """BASELINE configs[3] at full size: 1 M random triangles at 4096x4096, primary rays.  Out of the oracle's reach,
+    so checked through properties: culled front-to-back traversal == traversal of every leaf the reference visits;
+    the first nine frames of a scene cycle through the four node formats (binary / 4-wide, f32 / fp16) and must all be
+    the same frame; eight row tiles reassemble it."""
+    w = h = 4096
+    ds = DeviceScene(flatten(scenes.soup_scene()), Config(), builder=abi.BUILDER_SAH)
+    formats = set()
+    first = None
+    for i in range(9):
+        u8, _, st = ds.render(FLAT, w, h, want_f32=False)
+        formats.add(st["node_format"] & 5)
+        if first is None:
+            first = u8
+        else:
+            assert np.array_equal(u8, first), (i, st["node_format"])
+    assert formats == {0, 1, 4, 5} and not st["node_format"] & 256   # all four were used; the ninth frame is past calibration
+    ex, _, _ = ds.render(FLAT, w, h, want_f32=False, traversal=abi.TRAVERSAL_EXHAUSTIVE)
+    assert np.array_equal(ex, first)
+    hit = (first[..., :3].astype(np.int32).sum(-1) > 0).mean()
+    assert 0.05 < hit <= 1.0, hit
+    frame = np.zeros_like(first)
+    for part in range(8):
+        rows = [y for y in range(h) if (y // 8) % 8 == part]
+        u8, _, sp = ds.render(FLAT, w, h, tile=(part, 8, 8), want_f32=False)
+        frame[rows] = u8
+    assert np.array_equal(frame, first)
+    ds.close()
+
+
 # ---- GPU BLAS builder (rayca_amd/csrc/bvh_build.hip) ---------------------------------------------------------------
 @pytest.mark.parametrize("name", ["atrium", "soup64k", "soup_flat", "soup1m"])
 def test_gpu_builder_builds_the_host_builders_tree(gpu, name):
