@@ -588,23 +588,50 @@ __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, c
 }
 
 // ---- BRDFs: brdf/ggx.rs:58-129, brdf/lambertian.rs:7-16 -----------------------------------------
+// The reference spells these terms with libm compositions -- tan(acos(c))^2, powf(c, 4), powf(x, 5)
+// (ggx.rs:58-129) -- ~1500 VALU instructions per BRDF evaluation on this chip, a fifth of the bench frame's
+// arithmetic.  RAYCA_GGX_CLOSED_FORM (default) evaluates the same quantities in closed form,
+//   tan^2(acos c) = (1-c)(1+c)/c^2,   c^4 (a^2 + tan^2)^2 = (a^2 c^2 + (1-c)(1+c))^2,   x^5 = (x^2)^2 x,
+// each within 4e-7 of the exact value, where the f32 composition itself is only good to the rounding of acosf
+// amplified by 1/c (several percent at grazing half-vectors).  Shaded pixels are compared with the oracle -- which
+// keeps the reference's spelling -- at the 1e-4 tolerance of the parity tests; hit records are unaffected.
+// Special cases of the composition are kept: c == 0 gives D = 0 (cos^4 underflows first), c > 1 gives NaN (acosf).
+#ifndef RAYCA_GGX_CLOSED_FORM
+#define RAYCA_GGX_CLOSED_FORM 1
+#endif
 __device__ __forceinline__ float ggx_d(float a, F4 h, F4 n) {
   const float a2 = a * a;
   const float cos_theta = clampf(dot(h, n), 0.0f, 1.0f);
+#if RAYCA_GGX_CLOSED_FORM
+  const float q = a2 * (cos_theta * cos_theta) + (1.0f - cos_theta) * (1.0f + cos_theta);
+  const float denominator = q * q;
+  if (denominator == 0.0f || cos_theta == 0.0f) return 0.0f;
+#else
   const float theta = acosf(cos_theta);
   const float denominator = powf(cos_theta, 4.0f) * powf(a2 + powf(tanf(theta), 2.0f), 2.0f);
   if (denominator == 0.0f) return 0.0f;
+#endif
   return a2 * kFrac1Pi / denominator;
 }
 __device__ __forceinline__ float ggx_g1(float a, F4 omega, F4 n) {
   const float cos_theta = dot(omega, n);
   if (cos_theta <= 0.0f) return 0.0f;
+#if RAYCA_GGX_CLOSED_FORM
+  const float tan2 = cos_theta > 1.0f ? NAN : ((1.0f - cos_theta) * (1.0f + cos_theta)) / (cos_theta * cos_theta);
+  return 2.0f / (1.0f + sqrtf(1.0f + a * a * tan2));
+#else
   const float theta = acosf(cos_theta);
   return 2.0f / (1.0f + sqrtf(1.0f + a * a * powf(tanf(theta), 2.0f)));
+#endif
 }
 __device__ __forceinline__ Color ggx_f(Color ks, F4 omega_i, F4 h) {
   const float oh = fabsf(dot(omega_i, h));
+#if RAYCA_GGX_CLOSED_FORM
+  const float x = 1.0f - oh, x2 = x * x;
+  return ks + (white() - ks) * ((x2 * x2) * x);
+#else
   return ks + (white() - ks) * powf(1.0f - oh, 5.0f);
+#endif
 }
 __device__ __noinline__ Color surf_brdf(const ShadeCtx& s, F4 omega_i) {  // HitInfo::get_brdf  hit.rs:220-227
   if (s.kind == RAYCA_MATERIAL_PHONG) {  // lambertian::get_brdf
