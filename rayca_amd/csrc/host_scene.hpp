@@ -3,6 +3,7 @@
 // then conversion of the two-level BVH into the device layout.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -12,18 +13,24 @@
 
 namespace rayca {
 
-// VertexExt (rayca-geometry/src/vertex.rs:64-72) x3 + material, as uploaded: 48 words per primitive.
+// VertexExt (rayca-geometry/src/vertex.rs:64-72) x3 + material, as uploaded: 256 B per primitive, two 128-B
+// lines.  Everything a hit needs unless its material has a normal texture -- vertex colours, normals, uvs, material --
+// sits in the first line, tangents and bitangents in the second: an incoherent hit (bounce generations) costs one
+// line instead of the 2-3 a packed 192-B record straddles.
 struct PrimExt {
   float color[3][4];
   float normal[3][3];
-  float tangent[3][3];
-  float bitangent[3][3];
   float uv[3][2];
   uint32_t material;
   uint32_t kind;       // RAYCA_GEOMETRY_*
   uint32_t node;       // world-transform index (spheres)
+  uint32_t pad0[2];
+  float tangent[3][3];
+  float bitangent[3][3];
+  uint32_t pad1[14];
 };
-static_assert(sizeof(PrimExt) == 48 * 4, "PrimExt is 192 B");
+static_assert(sizeof(PrimExt) == 256, "PrimExt is 256 B");
+static_assert(offsetof(PrimExt, tangent) == 128, "the second line starts with the tangents");
 
 // BvhNode in the reference's layout (bvh/blas.rs:11-15): root 0, slot 1 unused, children adjacent.
 struct RefNode {

@@ -593,7 +593,7 @@ __device__ __forceinline__ void shade_hit(const DevScene& sc, const DRay& ray, c
 // arithmetic.  RAYCA_GGX_CLOSED_FORM (default) evaluates the same quantities in closed form,
 //   tan^2(acos c) = (1-c)(1+c)/c^2,   c^4 (a^2 + tan^2)^2 = (a^2 c^2 + (1-c)(1+c))^2,   x^5 = (x^2)^2 x,
 // each within 4e-7 of the exact value, where the f32 composition itself is only good to the rounding of acosf
-// amplified by 1/c (several percent at grazing half-vectors).  Shaded pixels are compared with the oracle -- which
+// amplified by 1/c (several percent at grazing half-vectors).  Shaded pixels are compared with the CPU restatement -- which
 // keeps the reference's spelling -- at the 1e-4 tolerance of the parity tests; hit records are unaffected.
 // Special cases of the composition are kept: c == 0 gives D = 0 (cos^4 underflows first), c > 1 gives NaN (acosf).
 #ifndef RAYCA_GGX_CLOSED_FORM
