@@ -209,7 +209,11 @@ def main():
         st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
         kms.append(st["kernel_ms"])
         tms.append(st["trace_kernel_ms"] / max(st["trace_kernel_launches"], 1))
-    trace_ms = float(np.mean(tms))
+        launches_per_frame = max(int(st["trace_kernel_launches"]), 1)
+    trace_ms = float(np.mean(tms))   # average duration of one traversal-kernel launch
+    # algorithmic bytes are counted over the frame: per launch they are the frame's bytes / its traversal launches
+    # (1 for the benchmark frame; a 4-bounce frame has 5 generations x (trace + shadow))
+    algo_bytes = algo_bytes / launches_per_frame
 
     t = torch.tensor([elapsed, float(rays_rank), float(algo_bytes), trace_ms], dtype=torch.float64,
                      device=dev if backend == "nccl" else "cpu")
@@ -253,7 +257,7 @@ def main():
                                     if world > 1 else "none")},
         "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from four generations up)" if wl_generations >= 4 else "k_generation (generation 0)"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4),
+                     "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4), "launches_per_frame": launches_per_frame,
                      "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),
                      "hits_shaded": int(counted["hits_shaded"]), "frame_kernel_ms": round(float(np.mean(kms)), 4)},
     }
