@@ -89,6 +89,7 @@ struct TraceLaunch {
   uint32_t* ovf;         // [entries over the LDS part][ovf_stride] dwords, or nullptr
   uint32_t lds_entries;
   uint32_t ovf_stride;   // total threads of the launch
+  uint32_t ticket;       // batches a wave takes from its work counter at a time (persistent kernels)
 };
 
 struct TraceCounters {

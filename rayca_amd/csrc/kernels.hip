@@ -672,24 +672,26 @@ __device__ __forceinline__ uint32_t xcc_id() {
 // the same L2), then steal from the others.  Placement only affects speed, never results.
 // Tickets: each of the 8 counters lives on its own 256-B line (kHeadStride dwords apart) -- atomics on
 // one line serialise in one L2 channel at ~12 ns each, which for 32k batches would be as long as the
-// whole kernel -- and one ticket covers kBatchesPerTicket consecutive batches.
+// whole kernel -- and one ticket covers `ticket` consecutive batches: two when the frame has batches to spare, one
+// when there are fewer batches than resident waves (a rank's share of a frame on eight GPUs): pairs would then
+// leave half the waves without work and double the time of the others.
 constexpr uint32_t kHeadStride = 64;
-constexpr uint32_t kBatchesPerTicket = 2;
 struct WorkCursor {
   uint32_t exhausted = 0;  // partitions found empty so far
   uint32_t next = 0, end = 0;  // batches of the current ticket still to do
 };
-__device__ __forceinline__ uint32_t next_batch(uint32_t* heads, uint32_t total, uint32_t home, WorkCursor& wc) {
+__device__ __forceinline__ uint32_t next_batch(uint32_t* heads, uint32_t total, uint32_t home, WorkCursor& wc, uint32_t ticket) {
   if (wc.next < wc.end) return wc.next++;
+  ticket = max(ticket, 1u);  // a zero ticket would never drain the counters
   while (wc.exhausted < 8u) {
     const uint32_t part = (home + wc.exhausted) & 7u;
     const uint32_t lo = (uint32_t)(((uint64_t)part * total) >> 3), hi = (uint32_t)(((uint64_t)(part + 1u) * total) >> 3);
     uint32_t idx = 0;
-    if (__lane_id() == 0) idx = atomicAdd(&heads[part * kHeadStride], kBatchesPerTicket);
+    if (__lane_id() == 0) idx = atomicAdd(&heads[part * kHeadStride], ticket);
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx < hi - lo) {
       wc.next = lo + idx + 1u;
-      wc.end = min(lo + idx + kBatchesPerTicket, hi);
+      wc.end = min(lo + idx + ticket, hi);
       return lo + idx;
     }
     wc.exhausted++;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
   const uint32_t nee_lights = (MODE == kModePath && fp.direct_sampler == RAYCA_SAMPLER_NEE) ? sc.light_count : 0u;
 
   for (;;) {
-    const uint32_t batch = next_batch(heads, total, home, wc);
+    const uint32_t batch = next_batch(heads, total, home, wc, tl.ticket);
     if (batch == RAYCA_NONE) break;
     bool live;
     uint32_t p = 0, key = 0;

@@ -4,9 +4,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from rayca_amd import Config, DeviceScene, flatten, scenes, abi
+from rayca_amd import Config, DeviceScene, IntegratorStrategy, flatten, scenes, abi
 W, H = 1920, 1080
-cfg = Config(max_depth=1)
+cfg = Config(max_depth=1) if (len(sys.argv) < 2 or sys.argv[1] != 'flat') else Config(integrator=IntegratorStrategy.Flat)
 desc = flatten(scenes.atrium_scene())
 dev = torch.device("cuda", 0)
 NH = 8
@@ -27,6 +27,7 @@ for parts in (1, 2, 4, 8):
         for i in range(K):
             j = i % inflight
             ds.render_device(cfg, W, H, outs[j].data_ptr(), 0, tile=tile, stream=streams[j].cuda_stream, context=j)
+        t_host = (time.perf_counter() - t0) / K * 1e3   # the host's share: enqueueing one frame
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / K * 1e3
-        print(f"parts {parts} frames in flight {inflight}: {t:.4f} ms/frame", flush=True)
+        print(f"parts {parts} frames in flight {inflight}: {t:.4f} ms/frame (host enqueue {t_host:.4f})", flush=True)
