@@ -67,38 +67,36 @@ __device__ __forceinline__ bool slab(float ax, float ay, float az, float bx, flo
 // candidate iff the reference's own leaf box passes `slab` (reference_candidate), this test only steers
 // the search and the padding of the boxes dominates its rounding error.
 struct FastRay {
-  float rdx, rdy, rdz, ox, oy, oz;  // rd and -(o*rd)
-  float ax, ay, az, bx, by, bz;     // fp16 boxes: t = h * (rd / scale) + (centre - o) * rd  (unused fields cost nothing)
+  float mx, my, mz, cx, cy, cz;  // plane distance t = coordinate * m + c
 };
-__device__ __forceinline__ FastRay make_fast(const DevScene& sc, const DRay& r) {
+// f32 boxes: t = b*rd - o*rd.  fp16 boxes hold (x - centre) * scale: t = h * (rd / scale) + (centre - o) * rd.
+__device__ __forceinline__ FastRay make_fast(const DevScene& sc, const DRay& r, bool half) {
   FastRay f;
-  f.rdx = r.rd.x; f.rdy = r.rd.y; f.rdz = r.rd.z;
-  f.ox = -(r.o.x * r.rd.x); f.oy = -(r.o.y * r.rd.y); f.oz = -(r.o.z * r.rd.z);
-  f.ax = r.rd.x * sc.half_inv_scale; f.ay = r.rd.y * sc.half_inv_scale; f.az = r.rd.z * sc.half_inv_scale;
-  f.bx = (sc.half_center[0] - r.o.x) * r.rd.x; f.by = (sc.half_center[1] - r.o.y) * r.rd.y; f.bz = (sc.half_center[2] - r.o.z) * r.rd.z;
+  if (half) {
+    f.mx = r.rd.x * sc.half_inv_scale; f.my = r.rd.y * sc.half_inv_scale; f.mz = r.rd.z * sc.half_inv_scale;
+    f.cx = (sc.half_center[0] - r.o.x) * r.rd.x; f.cy = (sc.half_center[1] - r.o.y) * r.rd.y; f.cz = (sc.half_center[2] - r.o.z) * r.rd.z;
+  } else {
+    f.mx = r.rd.x; f.my = r.rd.y; f.mz = r.rd.z;
+    f.cx = -(r.o.x * r.rd.x); f.cy = -(r.o.y * r.rd.y); f.cz = -(r.o.z * r.rd.z);
+  }
   return f;
 }
 // fp16 -> f32 is exact and free: fmaf((float)half, a, b) is one v_fma_mix_f32
 typedef _Float16 rc_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_cast(rc_h2, w).x; }
 __device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rc_h2, w).y; }
-__device__ __forceinline__ bool slab_half(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
-  const float t1x = __fmaf_rn(ax, f.ax, f.bx), t2x = __fmaf_rn(bx, f.ax, f.bx);
-  const float t1y = __fmaf_rn(ay, f.ay, f.by), t2y = __fmaf_rn(by, f.ay, f.by);
-  const float t1z = __fmaf_rn(az, f.az, f.bz), t2z = __fmaf_rn(bz, f.az, f.bz);
+__device__ __forceinline__ bool slab_fast(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
+  const float t1x = __fmaf_rn(ax, f.mx, f.cx), t2x = __fmaf_rn(bx, f.mx, f.cx);
+  const float t1y = __fmaf_rn(ay, f.my, f.cy), t2y = __fmaf_rn(by, f.my, f.cy);
+  const float t1z = __fmaf_rn(az, f.mz, f.cz), t2z = __fmaf_rn(bz, f.mz, f.cz);
   const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
   const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
   tmin_out = tmin;
   return tmax >= tmin && tmax > 0.0f;
 }
-__device__ __forceinline__ bool slab_fast(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
-  const float t1x = __fmaf_rn(ax, f.rdx, f.ox), t2x = __fmaf_rn(bx, f.rdx, f.ox);
-  const float t1y = __fmaf_rn(ay, f.rdy, f.oy), t2y = __fmaf_rn(by, f.rdy, f.oy);
-  const float t1z = __fmaf_rn(az, f.rdz, f.oz), t2z = __fmaf_rn(bz, f.rdz, f.oz);
-  const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-  const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-  tmin_out = tmin;
-  return tmax >= tmin && tmax > 0.0f;
+// the same arithmetic on decoded fp16 planes (make_fast folds centre and scale into m and c)
+__device__ __forceinline__ bool slab_half(float ax, float ay, float az, float bx, float by, float bz, const FastRay& f, float& tmin_out) {
+  return slab_fast(ax, ay, az, bx, by, bz, f, tmin_out);
 }
 
 // Triangle::intersects  rayca-geometry/src/triangle.rs:84-159 on world-space vertices (identical
@@ -418,7 +416,7 @@ key[i] = ka; key[j] = kb; ref[i] = ra; ref[j] = rb; \
 // later leaf test delays the cull bound.  Not kept.)
 template <bool ORDERED, bool FAST, bool SPH, bool WIDE, bool SPILL, bool STATS, bool HALF = false>
 __device__ __forceinline__ bool trace(const DevScene& sc, const DRay& r, float t_stop, NodeStack<SPILL>& st, DHit& hit, LaneCounters& cnt) {
-  const FastRay fr = make_fast(sc, r);
+  const FastRay fr = make_fast(sc, r, HALF);
   hit.t = INFINITY;
   hit.prim = RAYCA_NONE;
   hit.u = hit.v = 0.0f;
