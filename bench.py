@@ -255,7 +255,7 @@ def main():
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
                    "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, {B} finished frame(s) per collective, overlapped with rendering"
                                     if world > 1 else "none")},
-        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from four generations up)" if wl_generations >= 4 else "k_generation (generation 0)"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from three generations up)" if wl_generations >= 3 else "k_generation (generation 0)"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4), "launches_per_frame": launches_per_frame,
                      "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),

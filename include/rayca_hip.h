@@ -271,8 +271,8 @@ enum {
 
 enum {
   /* generation-by-generation rendering where the Config allows it (Flat; Pathtracer with Nee/None direct
-   * and Cosine/Hemisphere indirect sampling, one indirect sample per vertex, no roulette) -- FUSED up to three
-   * generations, WAVEFRONT from four (measured) -- else the stack machine */
+   * and Cosine/Hemisphere indirect sampling, one indirect sample per vertex, no roulette) -- FUSED up to two
+   * generations, WAVEFRONT from three (measured) -- else the stack machine */
   RAYCA_ENGINE_AUTO = 0,
   /* always the per-pixel stack machine (k_general): every IntegratorStrategy / SamplerStrategy the
    * reference has.  Same results as AUTO where both apply (tested); slower. */
