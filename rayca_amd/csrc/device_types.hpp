@@ -85,6 +85,12 @@ struct FrameParams {
 
 // per-launch traversal workspace: the node stack lives in LDS up to `lds_entries` entries per lane
 // (entry-major, one 1-KiB row per entry and block) and spills to `ovf` beyond that
+// one wave = one tile of 64 pixels: 2^W_LOG2 wide, 2^(6 - W_LOG2) high
+#ifndef RAYCA_TILE_W_LOG2
+#define RAYCA_TILE_W_LOG2 3
+#endif
+constexpr uint32_t kTileW = 1u << RAYCA_TILE_W_LOG2, kTileH = 64u >> RAYCA_TILE_W_LOG2;
+
 struct TraceLaunch {
   uint32_t* ovf;         // [entries over the LDS part][ovf_stride] dwords, or nullptr
   uint32_t lds_entries;

@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
     DRay ray;
     if (GEN0) {
       const uint32_t ty = batch / fp.tiles_x, tx = batch - ty * fp.tiles_x;
-      const uint32_t x = tx * 8u + (lane & 7u), r = ty * 8u + (lane >> 3);
+      const uint32_t x = tx * kTileW + (lane & (kTileW - 1u)), r = ty * kTileH + (lane >> RAYCA_TILE_W_LOG2);
       live = x < fp.width && r < fp.rows;
       const uint32_t y = ((r / fp.band) * fp.parts + fp.part) * fp.band + (r % fp.band);
       p = r * fp.width + x;
