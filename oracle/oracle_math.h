@@ -147,6 +147,12 @@ static inline V4 qconj(V4 q) { return mul4(q, v4(-1.0f, -1.0f, -1.0f, 1.0f)); }
 static inline float qlen(V4 q) { return sqrtf(dot4(q, q)); }
 static inline int q_is_normalized(V4 q) { return fabsf(qlen(q) - 1.0f) < 0.001f; }
 static inline V4 qnormalize(V4 q) { float l = qlen(q); return v4(q.x / l, q.y / l, q.z / l, q.w / l); }
+/* Quat::axis_angle  quat.rs:67-77 */
+static inline V4 q_axis_angle(V4 axis, float angle) {
+  float factor = sinf(angle / 2.0f);
+  V4 s = add4(mul4(axis, splat4(factor)), v4(0.0f, 0.0f, 0.0f, cosf(angle / 2.0f)));
+  return qnormalize(s);
+}
 
 /* ---- Trs  rayca-math/src/trs.rs ------------------------------------------------------------- */
 static inline Trs trs_identity(void) {
@@ -260,6 +266,47 @@ static inline V4 m4_point(const M4* m, V4 p) {
   for (int i = 0; i < 4; ++i) ret[i] = reduce_sum4(mul4(v4(m->m[i][0], m->m[i][1], m->m[i][2], m->m[i][3]), p));
   float den = ret[3] != 0.0f ? ret[3] : 1.0f;
   return point3(ret[0] / den, ret[1] / den, ret[2] / den);
+}
+/* impl_mul3!(Vec3, Mat4)  mat4.rs:296-320: the same macro with a w = 0 operand */
+static inline V4 m4_vec(const M4* m, V4 v) {
+  float ret[4];
+  for (int i = 0; i < 4; ++i) ret[i] = reduce_sum4(mul4(v4(m->m[i][0], m->m[i][1], m->m[i][2], m->m[i][3]), v));
+  float den = ret[3] != 0.0f ? ret[3] : 1.0f;
+  return vec3(ret[0] / den, ret[1] / den, ret[2] / den);
+}
+/* get_transpose  mat4.rs:131-137 */
+static inline M4 m4_transpose(const M4* m) {
+  M4 r;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r.m[i][j] = m->m[j][i];
+  return r;
+}
+/* Mat4::look_at  mat4.rs:81-95 (the Z axis points towards the eye) */
+static inline M4 m4_look_at(V4 target, V4 eye, V4 up) {
+  V4 z = vnormalize(vsub(eye, target));
+  V4 x = vnormalize(vcross(up, z));
+  V4 y = vcross(z, x);
+  V4 ne = vneg(eye);
+  M4 r = {{{x.x, x.y, x.z, x.w + dot4(x, ne)}, {y.x, y.y, y.z, y.w + dot4(y, ne)}, {z.x, z.y, z.z, z.w + dot4(z, ne)}, {0, 0, 0, 1}}};
+  return r;
+}
+/* From<&Mat4> for Quat  quat.rs:184-226 (Mat4::get_rotation  mat4.rs:117-119) */
+static inline V4 q_from_m4(const M4* m) {
+  V4 r;
+  float t = m->m[0][0] + m->m[1][1] + m->m[2][2];
+  if (t > 0.0f) {
+    float s = 0.5f / sqrtf(t + 1.0f);
+    r = v4((m->m[2][1] - m->m[1][2]) * s, (m->m[0][2] - m->m[2][0]) * s, (m->m[1][0] - m->m[0][1]) * s, 0.25f / s);
+  } else if (m->m[0][0] > m->m[1][1] && m->m[0][0] > m->m[2][2]) {
+    float s = 2.0f * sqrtf(1.0f + m->m[0][0] - m->m[1][1] - m->m[2][2]);
+    r = v4(0.25f * s, (m->m[0][1] + m->m[1][0]) / s, (m->m[0][2] + m->m[2][0]) / s, (m->m[2][1] - m->m[1][2]) / s);
+  } else if (m->m[1][1] > m->m[2][2]) {
+    float s = 2.0f * sqrtf(1.0f + m->m[1][1] - m->m[0][0] - m->m[2][2]);
+    r = v4((m->m[0][1] + m->m[1][0]) / s, 0.25f * s, (m->m[1][2] + m->m[2][1]) / s, (m->m[0][2] - m->m[2][0]) / s);
+  } else {
+    float s = 2.0f * sqrtf(1.0f + m->m[2][2] - m->m[0][0] - m->m[1][1]);
+    r = v4((m->m[0][2] + m->m[2][0]) / s, (m->m[1][2] + m->m[2][1]) / s, 0.25f * s, (m->m[1][0] - m->m[0][1]) / s);
+  }
+  return qnormalize(r);
 }
 /* Mul<Point3> for &Inversed<Trs>  trs.rs:372-381 */
 static inline V4 inv_trs_point(const Trs* t, V4 p) {

@@ -324,6 +324,10 @@ static inline int sphere_intersects(V4 center, float radius2, const Trs* trs, co
 /* ============================================================================================ */
 /* BvhPrimitive helpers  rayca-soft/src/bvh/primitive.rs:71-101                                   */
 /* ============================================================================================ */
+/* Triangle::new  triangle.rs:58-63: centroid = (v0 + v1 + v2) * 0.3333, in model space */
+static inline V4 tri_model_centroid(const V4 p[3]) {
+  return vscale(vadd(vadd(vec_from_point(p[0]), vec_from_point(p[1])), vec_from_point(p[2])), 0.3333f);
+}
 static inline V4 tri_min(const V4 p[3], const Trs* t) { /* triangle.rs:165-170 */
   V4 m = point3(FLT_MAX, FLT_MAX, FLT_MAX);
   m = min4(m, trs_point(t, p[0])); m = min4(m, trs_point(t, p[1])); m = min4(m, trs_point(t, p[2]));
@@ -1580,7 +1584,7 @@ static int32_t prims_from_triangle_mesh(const OracleScene* s, const RaycaSceneDe
       pr.ext[k].uv = d->uvs ? v2(d->uvs[2 * v], d->uvs[2 * v + 1]) : v2(0, 0);
     }
     /* Triangle::new centroid  triangle.rs:59-63 */
-    pr.centroid = vscale(vadd(vadd(vec_from_point(pr.p[0]), vec_from_point(pr.p[1])), vec_from_point(pr.p[2])), 0.3333f);
+    pr.centroid = tri_model_centroid(pr.p);
     pr.src = (*flat_counter)++;
     pv_push(out, &pr);
   }
@@ -1607,7 +1611,7 @@ static void prims_from_quad_light(const RaycaLight* l, uint32_t node, PrimVec* o
       pr.ext[k].bitangent = vec3(0, 0, 0);
       pr.ext[k].uv = v2(0, 0);
     }
-    pr.centroid = vscale(vadd(vadd(vec_from_point(pr.p[0]), vec_from_point(pr.p[1])), vec_from_point(pr.p[2])), 0.3333f);
+    pr.centroid = tri_model_centroid(pr.p);
     pr.src = (*flat_counter)++;
     pv_push(out, &pr);
   }
@@ -2028,4 +2032,73 @@ float oracle_aabb_intersects(const float a[3], const float b[3], const float ori
   AABB bx = {point3(a[0], a[1], a[2]), point3(b[0], b[1], b[2])};
   Ray ray = ray_new(point3(origin[0], origin[1], origin[2]), vec3(dir[0], dir[1], dir[2]));
   return aabb_intersects(&bx, &ray);
+}
+/* Triangle::{get_centroid,min,max}(trs)  triangle.rs:160-177 through the functions the scene path uses */
+void oracle_triangle_bounds(const float v[9], const RaycaTrs* trs, float centroid[3], float mn[3], float mx[3]) {
+  Trs tt = trs_from_abi(trs);
+  V4 p[3] = {point3(v[0], v[1], v[2]), point3(v[3], v[4], v[5]), point3(v[6], v[7], v[8])};
+  out3(trs_vec(&tt, tri_model_centroid(p)), centroid);
+  out3(tri_min(p, &tt), mn);
+  out3(tri_max(p, &tt), mx);
+}
+/* Sphere::{get_centroid,min,max}(trs)  sphere.rs:164-178 */
+void oracle_sphere_bounds(const float center[3], float radius, const RaycaTrs* trs, float centroid[3], float mn[3], float mx[3]) {
+  Trs tt = trs_from_abi(trs);
+  Prim pr;
+  memset(&pr, 0, sizeof pr);
+  pr.kind = RAYCA_GEOMETRY_SPHERE;
+  pr.center = point3(center[0], center[1], center[2]);
+  pr.radius = radius;
+  pr.radius2 = radius * radius;
+  float r = sphere_world_radius(&pr, &tt);
+  V4 c = trs_point(&tt, pr.center);
+  out3(c, centroid);
+  out3(sub4(c, vec3(r, r, r)), mn);
+  out3(add4(c, vec3(r, r, r)), mx);
+}
+/* BvhPrimitive::intersects(scene, ray)  primitive.rs:95-101 for the primitive whose flatten-order index is `src`:
+ * no BVH in front of it, as in the reference's own test (bvh/triangle.rs:83-114).  1 = hit, 0 = miss, -1 = no such primitive */
+int32_t oracle_scene_primitive_intersects(const OracleScene* s, uint32_t src, const float origin[3], const float dir[3], float* t, float uv[2]) {
+  Ray ray = ray_new(point3(origin[0], origin[1], origin[2]), vec3(dir[0], dir[1], dir[2]));
+  for (uint32_t b = 0; b < s->blas_count; ++b) {
+    const Blas* bl = &s->blass[b];
+    for (uint32_t i = 0; i < bl->prim_count; ++i) {
+      if (bl->prims[i].src != src) continue;
+      Hit h;
+      if (!prim_intersects(s, &bl->prims[i], &ray, &h)) return 0;
+      if (t) *t = h.depth;
+      if (uv) { uv[0] = h.uv.x; uv[1] = h.uv.y; }
+      return 1;
+    }
+  }
+  return -1;
+}
+/* ---- Mat4 / Quat known-answer hooks (rayca-math/src/mat4.rs:321-421, quat.rs:301-396); matrices are 16 floats, row-major */
+static M4 m4_in(const float m[16]) { M4 r; memcpy(r.m, m, 64); return r; }
+void oracle_mat4_identity(float o[16]) { M4 r = m4_identity(); memcpy(o, r.m, 64); }
+void oracle_mat4_mul(const float a[16], const float b[16], float o[16]) { M4 x = m4_in(a), y = m4_in(b); M4 r = m4_mul(&x, &y); memcpy(o, r.m, 64); }
+void oracle_mat4_from_scale(const float s[3], float o[16]) { M4 r = m4_from_scale(vec3(s[0], s[1], s[2])); memcpy(o, r.m, 64); }
+void oracle_mat4_from_translation(const float t[3], float o[16]) { M4 r = m4_from_translation(vec3(t[0], t[1], t[2])); memcpy(o, r.m, 64); }
+void oracle_mat4_transpose(const float m[16], float o[16]) { M4 x = m4_in(m); M4 r = m4_transpose(&x); memcpy(o, r.m, 64); }
+void oracle_mat4_look_at(const float target[3], const float eye[3], const float up[3], float o[16]) {
+  M4 r = m4_look_at(vec3(target[0], target[1], target[2]), vec3(eye[0], eye[1], eye[2]), vec3(up[0], up[1], up[2]));
+  memcpy(o, r.m, 64);
+}
+void oracle_mat4_get_rotation(const float m[16], float o[4]) { M4 x = m4_in(m); V4 q = q_from_m4(&x); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
+void oracle_mat4_mul_vec3(const float m[16], const float v[3], float o[3]) { M4 x = m4_in(m); out3(m4_vec(&x, vec3(v[0], v[1], v[2])), o); }
+void oracle_mat4_mul_point3(const float m[16], const float p[3], float o[3]) { M4 x = m4_in(m); out3(m4_point(&x, point3(p[0], p[1], p[2])), o); }
+void oracle_quat_axis_angle(const float axis[3], float angle, float o[4]) { V4 q = q_axis_angle(vec3(axis[0], axis[1], axis[2]), angle); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
+void oracle_quat_conjugate(const float q[4], float o[4]) { V4 r = qconj(v4(q[0], q[1], q[2], q[3])); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+void oracle_quat_normalize(const float q[4], float o[4]) { V4 r = qnormalize(v4(q[0], q[1], q[2], q[3])); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+int32_t oracle_quat_is_normalized(const float q[4]) { return q_is_normalized(v4(q[0], q[1], q[2], q[3])); }
+float oracle_quat_dot(const float a[4], const float b[4]) { return dot4(v4(a[0], a[1], a[2], a[3]), v4(b[0], b[1], b[2], b[3])); }
+float oracle_quat_len(const float q[4]) { return qlen(v4(q[0], q[1], q[2], q[3])); }
+/* Vec3 arithmetic and min/max  vec3.rs:556-573 */
+void oracle_vec3_arith(const float a[3], const float b[3], float s, float add[3], float sub[3], float mul[3], float div[3], float neg[3]) {
+  V4 x = vec3(a[0], a[1], a[2]), y = vec3(b[0], b[1], b[2]);
+  out3(vadd(x, y), add); out3(vsub(y, x), sub); out3(vscale(x, s), mul); out3(vdivf(y, s), div); out3(vneg(x), neg);
+}
+void oracle_vec3_min_max(const float a[3], const float b[3], float mn[3], float mx[3]) {
+  V4 x = vec3(a[0], a[1], a[2]), y = vec3(b[0], b[1], b[2]);
+  out3(min4(x, y), mn); out3(max4(x, y), mx);
 }

@@ -100,6 +100,32 @@ int32_t oracle_triangle_intersects(const float verts[9], const RaycaTrs* trs, co
 int32_t oracle_sphere_intersects(const float center[3], float radius, const RaycaTrs* trs,
                                  const float origin[3], const float dir[3], float* t,
                                  float point[3]);
+/* Triangle / Sphere ::get_centroid, min, max under `trs` (triangle.rs:160-177, sphere.rs:164-178) */
+void oracle_triangle_bounds(const float verts[9], const RaycaTrs* trs, float centroid[3], float mn[3], float mx[3]);
+void oracle_sphere_bounds(const float center[3], float radius, const RaycaTrs* trs, float centroid[3], float mn[3], float mx[3]);
+/* BvhPrimitive::intersects(scene, ray) of the primitive with flatten-order index `src`, without any BVH
+ * (bvh/triangle.rs:83-114): 1 hit, 0 miss, -1 no such primitive */
+int32_t oracle_scene_primitive_intersects(const OracleScene* s, uint32_t src, const float origin[3], const float dir[3], float* t, float uv[2]);
+/* Mat4 (row-major, 16 floats)  rayca-math/src/mat4.rs */
+void oracle_mat4_identity(float out[16]);
+void oracle_mat4_mul(const float a[16], const float b[16], float out[16]);
+void oracle_mat4_from_scale(const float s[3], float out[16]);
+void oracle_mat4_from_translation(const float t[3], float out[16]);
+void oracle_mat4_transpose(const float m[16], float out[16]);
+void oracle_mat4_look_at(const float target[3], const float eye[3], const float up[3], float out[16]);
+void oracle_mat4_get_rotation(const float m[16], float out[4]);
+void oracle_mat4_mul_vec3(const float m[16], const float v[3], float out[3]);
+void oracle_mat4_mul_point3(const float m[16], const float p[3], float out[3]);
+/* Quat  rayca-math/src/quat.rs */
+void oracle_quat_axis_angle(const float axis[3], float angle, float out[4]);
+void oracle_quat_conjugate(const float q[4], float out[4]);
+void oracle_quat_normalize(const float q[4], float out[4]);
+int32_t oracle_quat_is_normalized(const float q[4]);
+float oracle_quat_dot(const float a[4], const float b[4]);
+float oracle_quat_len(const float q[4]);
+/* Vec3 arithmetic: a+b, b-a, a*s, b/s, -a; lane-wise min / max  (vec3.rs:556-573) */
+void oracle_vec3_arith(const float a[3], const float b[3], float s, float add[3], float sub[3], float mul[3], float div[3], float neg[3]);
+void oracle_vec3_min_max(const float a[3], const float b[3], float mn[3], float mx[3]);
 /* AABB::intersects: returns tmin or f32::MAX */
 float oracle_aabb_intersects(const float a[3], const float b[3], const float origin[3],
                              const float dir[3]);

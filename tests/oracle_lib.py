@@ -83,6 +83,15 @@ def load():
     lib.oracle_rng_f32.argtypes = [C.c_uint32] * 2
     lib.oracle_sphere_intersects.argtypes = [C.c_void_p, C.c_float, P(abi.RaycaTrs), C.c_void_p, C.c_void_p,
                                              P(C.c_float), C.c_void_p]
+    VP = C.c_void_p
+    lib.oracle_sphere_bounds.argtypes = [VP, C.c_float, P(abi.RaycaTrs), VP, VP, VP]
+    lib.oracle_triangle_bounds.argtypes = [VP, P(abi.RaycaTrs), VP, VP, VP]
+    lib.oracle_scene_primitive_intersects.restype = C.c_int32
+    lib.oracle_scene_primitive_intersects.argtypes = [VP, C.c_uint32, VP, VP, P(C.c_float), VP]
+    lib.oracle_quat_axis_angle.argtypes = [VP, C.c_float, VP]
+    lib.oracle_quat_dot.restype = C.c_float
+    lib.oracle_quat_len.restype = C.c_float
+    lib.oracle_vec3_arith.argtypes = [VP, VP, C.c_float] + [VP] * 5
     _lib = lib
     return lib
 
