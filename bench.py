@@ -1,21 +1,31 @@
 """bench.py -- Mrays/s and ms/frame of the rayca hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload atrium|soup|cornell|box]
+    python bench.py --gpus N --steps K --warmup W [--workload atrium|soup|cornell|box|atrium4k]
 
-A "step" is one frame: every rank renders its rows of the frame with the HIP kernels (scene and BVH
-already resident in HBM) and rank 0 receives the gathered RGBA8 frame (one RCCL gather per frame,
-N > 1 only).  Default workload = the configuration BASELINE.json's metric is quoted on:
-1920x1080, primary + 1 shadow ray per hit (Pathtracer max_depth=1, NEE, one point light), 1 spp, on
-the ~272k-triangle procedural atrium -- a STAND-IN for Sponza, which is not available offline.
+A "step" is one frame: every rank renders its rows of the frame with the HIP kernels (scene and BVH already resident
+in HBM) and rank 0 receives the gathered RGBA8 frame (N > 1: ONE RCCL gather per frame, at frame end).  Default
+workload = the configuration BASELINE.json's metric is quoted on: 1920x1080, primary + 1 shadow ray per hit (Pathtracer
+max_depth=1, NEE, one point light), 1 spp, on the ~272k-triangle procedural atrium -- a STAND-IN for Sponza, which is
+not available offline.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (rayca_amd/launcher.py: plain
+child processes, started before anything touches a GPU); under `python -m torch.distributed.run` the ranks come from
+the launcher's environment as usual.
 
 One JSON line on rank 0:
-  value      whole-job Mrays/s = rays traced by all ranks in K steps / max-over-ranks wall time
-  roofline   dominant kernel k_generation (generation 0: camera rays + traversal + shading + shadow
-             rays): algorithmic bytes per launch (32 B per box test + 36 B per triangle test + 272 B
-             per shaded hit + 4 B per pixel, counted by the instrumented variant of the same kernel)
-             / mean launch duration from HIP events on the launch stream, against 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (port of the reference algorithm, per-test vertex transforms, all host
-             cores) on an evenly spaced subset of the same frame's rows; rank 0, N=1 only
+  value         whole-job Mrays/s = rays traced by all ranks in K steps / max-over-ranks wall time, with ONE gather per
+                frame for N > 1 (`config.frame_gather`); the same K steps with four frames per collective are timed as
+                well and reported next to it (`config.gather_batched`) -- never as `value`
+  roofline      dominant kernel (k_generation, generation 0: camera rays + traversal + shading + shadow rays): launch
+                duration from HIP events on the launch stream, priced against every hardware limit the kernel could
+                hit -- VALU issue, L1 (vector cache) bytes, L2 fill, HBM traffic, compulsory HBM bytes; `bound` names
+                the one it is closest to and `frac` is that fraction (<= 1).  The per-launch counter values come from
+                the committed rocprofv3 --pmc passes of this same command (profiles/pmc_counters_<workload>.json).
+                SURVEY 8(d)'s algorithmic bytes (32 B per box test + 36 B per triangle test + 272 B per shaded hit +
+                4 B per pixel, counted by the instrumented instantiation of the same kernel) are kept as
+                `algorithmic_access_rate`: they are served by L1/L2, not by HBM.
+  cpu_baseline  the CPU oracle (port of the reference algorithm, per-test vertex transforms, all host cores of this
+                job's share) on an evenly spaced subset of the same frame's rows; rank 0, N = 1 only
 """
 from __future__ import annotations
 
@@ -28,7 +38,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E 8 TB/s peak (6.3 TB/s achievable)
+L2_PEAK_GBS = 34500.0          # L2 aggregate, 8 XCDs
+CLOCK_HZ = 2.4e9               # max engine clock
+CUS, SIMDS = 256, 1024
+L1_PEAK_GBS = CUS * 64 * CLOCK_HZ / 1e9   # one 64-B line per clock and CU: 39.3 TB/s
+VALU_ISSUE_CYCLES = 4          # a wave64 VALU instruction occupies its SIMD for 4 cycles
 
 
 def workload_config(name):
@@ -51,7 +67,7 @@ def workload_config(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -63,10 +79,48 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently (frame contexts + streams); 0 = 2 on one GPU, 4 (the HIP hardware queues) with more")
     ap.add_argument("--gather-batch", type=int, default=4,
-                    help="N > 1: finished frames gathered per collective (1 = one gather per frame)")
+                    help="N > 1: frames per collective of the SECOND timed run (the first, `value`, always gathers every frame on its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def roofline_limits(workload, builder, launch_ms, compulsory_bytes):
+    """Fractions of the hardware limits the dominant kernel runs at, from the committed per-launch PMC counters of this
+    workload and the launch duration measured live.  Returns (limits dict, source path) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_counters_{workload}.json")
+    if builder != "sah" or not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path))
+    c = pmc["counters_per_launch"]
+    t = launch_ms * 1e-3
+    gbs = lambda b: b / t / 1e9   # noqa: E731
+    hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0   # KiB; gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+    limits = {
+        "valu_issue": {"achieved": round(c["SQ_INSTS_VALU"] / t / 1e9, 2), "peak": round(SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9, 1), "unit": "G wave-instr/s",
+                       "how": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)"},
+        "l1_bytes": {"achieved": round(gbs(c["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0), 1), "peak": round(L1_PEAK_GBS, 1), "unit": "GB/s",
+                     "how": "TCP_TOTAL_CACHE_ACCESSES x 64 B / launch time; peak 64 B/clk/CU x 256 CUs x 2.4 GHz"},
+        "l2_fill": {"achieved": round(gbs(c["TCP_TCC_READ_REQ_sum"] * 64.0), 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                    "how": "TCP_TCC_READ_REQ x 64 B / launch time"},
+        "hbm_traffic": {"achieved": round(gbs(hbm_bytes), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "how": "(2 x FETCH_SIZE + WRITE_SIZE) KiB from separate --pmc passes / launch time"},
+        "hbm_compulsory": {"achieved": round(gbs(compulsory_bytes), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "how": "scene (nodes + triangles + shading records) read once + path records + pixels written once / launch time"},
+    }
+    for v in limits.values():
+        v["frac"] = round(v["achieved"] / v["peak"], 4)
+    lanes = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(64.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0), 1.0)
+    return {"limits": limits, "valu_lane_activity": round(lanes, 3), "hbm_traffic_bytes": int(hbm_bytes),
+            "pmc_launch_ms": pmc.get("launch_ms_under_pmc")}, os.path.relpath(path, ROOT)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks ourselves -- before torch or HIP are imported, so this process never owns a device
+        from rayca_amd.launcher import relaunch_self
+        sys.exit(relaunch_self(args.gpus))
 
     import numpy as np
     import torch
@@ -122,55 +176,89 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(F)]   # render kernels, one stream per frame in flight
     stream = streams[0]
     comm = torch.cuda.Stream(dev)                           # frame gather (RCCL)
-    counter = [0]
     gather_dev = dev if backend == "nccl" else torch.device("cpu")
-    # N > 1: finished frames are gathered B at a time with ONE collective (a rank's rows of a 1080p frame are 1 MB at
-    # 8 ranks: per-call latency and the all-rank synchronisation of a collective cost more than its bytes).  Frames are
-    # rendered straight into slot b of one of two batch buffers; the gather of a batch overlaps the next batch's rendering.
-    B = max(1, min(args.gather_batch, 8)) if world > 1 else 1
-    gatherer = FrameGatherer(H, W, args.band_rows, gather_dev, batch=B) if world > 1 else None
-    sends = [torch.zeros((B, gatherer.max_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else []
-    frames = [torch.empty((B, H, W, 4), dtype=torch.uint8, device=gather_dev) for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
-    ev_render = [[torch.cuda.Event() for _ in range(B)] for _ in range(2)]
-    ev_gather = [torch.cuda.Event() for _ in range(2)]
-    for e in ev_gather:
-        e.record(comm)
 
-    def flush(k, n):
-        """gather the first n frames' worth of batch buffer k (always the whole buffer: one message shape)"""
-        with torch.cuda.stream(comm):
-            for e in ev_render[k][:n]:
-                comm.wait_event(e)
-            if backend == "nccl":
-                got = gatherer.gather_batch(sends[k], frames[k])
-            else:  # rehearsal: gloo gathers host tensors
-                comm.synchronize()
-                got = gatherer.gather_batch(sends[k].cpu(), frames[k])
-            ev_gather[k].record(comm)
-        return got
+    class GatherLoop:
+        """K frames, B finished frames per collective.  B = 1 is the north-star shape: one gather per frame, at frame
+        end.  Frames are rendered straight into slot b of one of two send buffers; the gather of one buffer runs on the
+        comm stream and overlaps the rendering into the other."""
 
-    def step(want_stats=False):
-        i = counter[0]
-        counter[0] += 1
-        c = i % F
-        st_c = streams[c]
-        if world == 1:
+        def __init__(self, B):
+            self.B = B
+            self.counter = 0
+            self.gatherer = FrameGatherer(H, W, args.band_rows, gather_dev, batch=B)
+            self.sends = [torch.zeros((B, self.gatherer.max_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.frames = [torch.empty((B, H, W, 4), dtype=torch.uint8, device=gather_dev) if rank == 0 else None for _ in range(2)]
+            self.ev_render = [[torch.cuda.Event() for _ in range(B)] for _ in range(2)]
+            self.ev_gather = [torch.cuda.Event() for _ in range(2)]
+            for e in self.ev_gather:
+                e.record(comm)
+
+        def flush(self, k, n):
+            with torch.cuda.stream(comm):
+                for e in self.ev_render[k][:n]:
+                    comm.wait_event(e)
+                if backend == "nccl":
+                    got = self.gatherer.gather_batch(self.sends[k], self.frames[k])
+                else:  # rehearsal: gloo gathers host tensors
+                    comm.synchronize()
+                    got = self.gatherer.gather_batch(self.sends[k].cpu(), self.frames[k])
+                self.ev_gather[k].record(comm)
+            return got
+
+        def step(self):
+            i = self.counter
+            self.counter += 1
+            c = i % F
+            st_c = streams[c]
+            b, k = i % self.B, (i // self.B) % 2
+            buf = self.sends[k][b, :my_rows]
             with torch.cuda.stream(st_c):
-                st = ds.render_device(cfg, W, H, outs[c].data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, want_stats=want_stats, context=c)
-            return st, outs[c]
-        b, k = i % B, (i // B) % 2
-        buf = sends[k][b, :my_rows]
-        with torch.cuda.stream(st_c):
-            st_c.wait_event(ev_gather[k])   # the previous gather out of this batch buffer has finished
-            st = ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, want_stats=want_stats, context=c)
-            ev_render[k][b].record(st_c)
-        return st, (flush(k, B) if b == B - 1 else None)
+                st_c.wait_event(self.ev_gather[k])   # the previous gather out of this send buffer has finished
+                ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, context=c)
+                self.ev_render[k][b].record(st_c)
+            return self.flush(k, self.B) if b == self.B - 1 else None
 
-    def drain():
-        """gather what an incomplete batch holds and start the next step on a batch boundary"""
-        if world > 1 and counter[0] % B:
-            flush((counter[0] // B) % 2, counter[0] % B)
-        counter[0] = 0
+        def drain(self):
+            """gather what an incomplete batch holds and start the next step on a batch boundary"""
+            if self.counter % self.B:
+                self.flush((self.counter // self.B) % 2, self.counter % self.B)
+            self.counter = 0
+
+    class LocalLoop:
+        """N = 1: no exchange, the frame stays in device memory."""
+        B = 1
+
+        def __init__(self):
+            self.counter = 0
+
+        def step(self):
+            c = self.counter % F
+            self.counter += 1
+            with torch.cuda.stream(streams[c]):
+                ds.render_device(cfg, W, H, outs[c].data_ptr(), 0, tile=tile, stream=streams[c].cuda_stream, context=c)
+            return outs[c]
+
+        def drain(self):
+            self.counter = 0
+
+    def timed(loop):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides."""
+        for _ in range(args.warmup):
+            loop.step()
+        loop.drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.step()
+        loop.drain()   # every one of the K frames is gathered inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
 
     # the scene times binary against 4-wide nodes on its first large frames (RaycaStats.node_format bit 8) and then
     # keeps the faster: let that finish before anything is timed
@@ -188,23 +276,17 @@ def main():
     rays_rank = counted["rays_primary"] + counted["rays_shadow"] + counted["rays_bounce"]
     algo_bytes = 32 * counted["boxes_tested"] + 36 * counted["triangles_tested"] + 272 * counted["hits_shaded"] + 4 * my_rows * W
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, frame = step()
-    drain()   # every one of the K frames is gathered inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    if world == 1:
+        elapsed = timed(LocalLoop())
+        elapsed_batched, B2 = None, 1
+    else:
+        elapsed = timed(GatherLoop(1))                       # `value`: one gather per frame
+        B2 = max(1, min(args.gather_batch, 8))
+        elapsed_batched = timed(GatherLoop(B2)) if B2 > 1 else None
+
     # kernel durations with HIP events on the launch stream (separate loop: the events force a sync per step)
     kms, tms = [], []
+    launches_per_frame = 1
     for _ in range(max(3, min(args.steps, 20))):
         st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
         kms.append(st["kernel_ms"])
@@ -215,23 +297,29 @@ def main():
     # (1 for the benchmark frame; a 4-bounce frame has 5 generations x (trace + shadow))
     algo_bytes = algo_bytes / launches_per_frame
 
-    t = torch.tensor([elapsed, float(rays_rank), float(algo_bytes), trace_ms], dtype=torch.float64,
-                     device=dev if backend == "nccl" else "cpu")
+    t = torch.tensor([elapsed, elapsed_batched or 0.0, float(rays_rank)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, rays_total = float(tmax[0]), float(tsum[1])
+        elapsed_max, elapsed_batched_max, rays_total = float(tmax[0]), float(tmax[1]), float(tsum[2])
     else:
-        elapsed_max, rays_total = elapsed, float(rays_rank)
+        elapsed_max, elapsed_batched_max, rays_total = elapsed, 0.0, float(rays_rank)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
     mrays = rays_total * args.steps / elapsed_max / 1e6
-    achieved = algo_bytes / (trace_ms * 1e-3) / 1e9
+    algo_rate = algo_bytes / (trace_ms * 1e-3) / 1e9
+    # what MUST cross the HBM interface once per launch: the scene's arrays in, path records and pixels out
+    is_path = int(getattr(cfg, "integrator", 5)) == 5
+    records = (16 + 16 + 4) * my_rows * W * max(wl_generations, 1) if is_path else 0   # direct colour, radiance factor, state per pixel and depth
+    # (only the node format the frame traverses: the scene keeps four; generation 0 decides for the one-launch frames)
+    n_nodes, n_tris = int(info["node_count"]), int(info["triangle_count"])
+    node_bytes = {0: 64 * n_nodes, 1: 128 * n_nodes // 3, 4: 32 * n_nodes, 5: 64 * n_nodes // 3}[node_format & 5]
+    compulsory = node_bytes + (36 + 256 + 8) * n_tris + records + 4 * my_rows * W
     result = {
         "metric": "Mrays/sec (primary+shadow), 1920x1080 Sponza 1spp" if args.workload == "atrium" else f"Mrays/sec ({args.workload})",
         "value": round(mrays, 3),
@@ -253,26 +341,36 @@ def main():
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
-                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, {B} finished frame(s) per collective, overlapped with rendering"
-                                    if world > 1 else "none")},
-        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from three generations up)" if wl_generations >= 3 else "k_generation (generation 0)"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": int(algo_bytes), "launch_ms": round(trace_ms, 4), "launches_per_frame": launches_per_frame,
-                     "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),
-                     "hits_shaded": int(counted["hits_shaded"]), "frame_kernel_ms": round(float(np.mean(kms)), 4)},
+                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, ONE collective per frame at frame end, on its own stream"
+                                    if world > 1 else "none"),
+                   "launched_by": "torch.distributed.run / environment" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py (rayca_amd/launcher.py)" if world > 1 else "single process")},
+        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from three generations up)" if wl_generations >= 3 else "k_generation (generation 0)"),
+                     "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
+                     "launch_ms": round(trace_ms, 4), "launches_per_frame": launches_per_frame, "frame_kernel_ms": round(float(np.mean(kms)), 4),
+                     "algorithmic_access_rate": {"bytes_per_launch": int(algo_bytes), "GBps": round(algo_rate, 1), "x_hbm_peak": round(algo_rate / HBM_PEAK_GBS, 3),
+                                                 "note": "SURVEY 8(d): every node and triangle a ray touches; served by L1/L2 (the tree is cache resident), so this is an access rate, not an HBM fraction",
+                                                 "boxes_tested": int(counted["boxes_tested"]), "triangles_tested": int(counted["triangles_tested"]),
+                                                 "hits_shaded": int(counted["hits_shaded"])},
+                     "compulsory_bytes_per_launch": compulsory},
     }
-    # HBM traffic cannot be read from inside this process: it comes from the committed rocprofv3 --pmc
-    # passes over this same workload (profiles/pmc_traffic_<workload>.json), per launch like `achieved`
-    pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
-    if world == 1 and args.builder == "sah" and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
-        result["roofline"]["traffic"] = traffic
-        result["roofline"]["traffic_source"] = os.path.relpath(pmc, ROOT)
-        # `frac` prices every node and triangle a ray touches against HBM; the trees of these scenes are L2/MALL
-        # resident, so what actually crosses the HBM interface is this much smaller fraction of peak
-        result["roofline"]["traffic_frac_of_peak"] = round(traffic / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        result["roofline"]["note"] = ("working set is cache resident: frac > 1 means algorithmic bytes are served by L2/MALL; the kernel is bound by "
-                                      "dependent-fetch latency (PMC: profiles/*pmc_summary.json, DESIGN.md section 8)")
+    if world > 1 and elapsed_batched is not None:
+        result["config"]["gather_batched"] = {"frames_per_collective": B2, "ms_per_step": round(elapsed_batched_max / args.steps * 1e3, 4),
+                                              "Mrays_per_s": round(rays_total * args.steps / elapsed_batched_max / 1e6, 3),
+                                              "note": "the same K frames, B finished frames per collective (fewer rendezvous); reported for comparison, not as `value`"}
+    rl = result["roofline"]
+    lim, src = roofline_limits(args.workload, args.builder, trace_ms, compulsory) if world == 1 else (None, None)
+    if lim:
+        rl.update(lim)
+        rl["pmc_source"] = src
+        name, top = max(lim["limits"].items(), key=lambda kv: kv[1]["frac"])
+        rl["bound"] = {"valu_issue": "valu", "l1_bytes": "l1", "l2_fill": "l2", "hbm_traffic": "hbm", "hbm_compulsory": "hbm"}[name]
+        rl["achieved"], rl["peak"], rl["unit"], rl["frac"] = top["achieved"], top["peak"], top["unit"], top["frac"]
+        rl["traffic"] = lim["hbm_traffic_bytes"]
+        rl["hbm_frac"] = lim["limits"]["hbm_traffic"]["frac"]
+    else:   # no counter file for this workload / builder / rank count: the compulsory-bytes HBM figure is what can be stated
+        a = compulsory / (trace_ms * 1e-3) / 1e9
+        rl["achieved"], rl["peak"], rl["frac"] = round(a, 1), HBM_PEAK_GBS, round(a / HBM_PEAK_GBS, 4)
+        rl["note"] = "no PMC counter file for this configuration: frac prices the compulsory HBM bytes only"
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(desc, cfg, W, H, args.cpu_seconds)
     print(json.dumps(result), flush=True)
@@ -302,8 +400,8 @@ def cpu_baseline(desc, cfg, W, H, budget_s):
     rays = st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
     return {"value": round(rays / st["seconds"] / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"every {parts}-th row of the same {W}x{H} frame ({st['rows_rendered']} rows, {rays} rays, "
-                      f"{st['seconds']:.2f} s wall); per-test vertex transforms as in the reference; BVH build excluded "
-                      "like the reference's own timer (scene.rs:101,152)"}
+                      f"{st['seconds']:.2f} s wall); per-test vertex transforms as in the reference, on the reference's own "
+                      "(origin-seeded) tree; BVH build excluded like the reference's own timer (scene.rs:101,152)"}
 
 
 if __name__ == "__main__":

@@ -79,7 +79,8 @@ struct FrameParams {
   // Config
   uint32_t integrator, direct_sampler, indirect_sampler, light_samples, light_stratify, strate_count;
   uint32_t max_depth, russian_roulette, seed, spp, sample;
-  float sub_x, sub_y;           // ix*step + offset, iy*step + offset of this sample (scene.rs:125-137)
+  float sub_step_x, sub_step_y; // ix*step, iy*step of this sample; the kernel evaluates (x + ix*step) + offset, the reference's
+  float sub_offset;             // association (scene.rs:125-137): folding the two terms on the host differs by 1 ulp for spp = 2, 3, 5, 9 ...
   float inv_gamma;
 };
 

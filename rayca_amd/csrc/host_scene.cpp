@@ -398,7 +398,7 @@ struct DevBuilder {
       b.a = point3(kNowhere, kNowhere, kNowhere);
       b.b = b.a;
     }
-    if (pad_rel > 0.0f && b.a.x <= b.b.x) {
+    if (pad_rel > 0.0f && b0.a.x <= b0.b.x) {  // (the nowhere box stays a point: padding would make it enterable)
       const float* lo[3] = {&b0.a.x, &b0.a.y, &b0.a.z};
       const float* hi[3] = {&b0.b.x, &b0.b.y, &b0.b.z};
       float* plo[3] = {&b.a.x, &b.a.y, &b.a.z};
@@ -1058,7 +1058,10 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       k = std::max(-100, std::min(100, k));
       s.half_scale = std::ldexp(1.0f, k);
       auto cv = [&](float x, int axis, bool up) -> uint16_t {
-        if (!(x == x) || std::fabs(x) >= 1e17f) return 0x7E00u;  // "nowhere" boxes and NaNs: never entered
+        // only NaNs are unenterable here; the "nowhere" slots are recognised box by box below.  Finite coordinates beyond
+        // the fp16 range saturate OUTWARD (to_half_directed: max -> +inf, min -> -inf), so the box stays conservative
+        // and the frame cannot depend on the node format chosen, whatever the scene's extent.
+        if (!(x == x)) return 0x7E00u;
         return to_half_directed(((double)x - (double)s.half_center[axis]) * (double)s.half_scale, up);
       };
       s.dev_nodes_h.resize(s.dev_nodes.size());
@@ -1068,10 +1071,14 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           DevNodeH& h = s.dev_nodes_h[i];
           // q: l.min xyz, l.max xyz, r.min xyz, r.max xyz
           for (int j = 0; j < 12; ++j) h.h[j] = cv(n.q[j], j % 3, (j / 3) & 1);
-          // an inverted (empty) box must stay unenterable after outward rounding
-          for (int side = 0; side < 2; ++side)
-            if (!(n.q[side * 6] <= n.q[side * 6 + 3]))
+          // an inverted (empty) box and the zero-size "nowhere" box of an unused slot must stay unenterable after
+          // outward rounding
+          for (int side = 0; side < 2; ++side) {
+            bool nowhere = true;
+            for (int j = 0; j < 6; ++j) nowhere = nowhere && n.q[side * 6 + j] == kNowhere;
+            if (nowhere || !(n.q[side * 6] <= n.q[side * 6 + 3]))
               for (int j = 0; j < 6; ++j) h.h[side * 6 + j] = 0x7E00u;
+          }
           h.left = n.left;
           h.right = n.right;
         }
@@ -1083,7 +1090,10 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           DevNode4H& h = s.dev_nodes4_h[i];
           for (int a = 0; a < 3; ++a)
             for (int c = 0; c < 4; ++c) {
-              const bool empty = !(n.lo[0][c] <= n.hi[0][c]);
+              bool empty = !(n.lo[0][c] <= n.hi[0][c]);
+              if (n.lo[0][c] == kNowhere && n.hi[0][c] == kNowhere && n.lo[1][c] == kNowhere && n.hi[1][c] == kNowhere && n.lo[2][c] == kNowhere &&
+                  n.hi[2][c] == kNowhere)
+                empty = true;  // unused slot (WideBuilder)
               h.lo[a][c] = empty ? 0x7E00u : cv(n.lo[a][c], a, false);
               h.hi[a][c] = empty ? 0x7E00u : cv(n.hi[a][c], a, true);
             }

@@ -724,8 +724,8 @@ __device__ __forceinline__ void finalize_pixel(const FrameParams& fp, Color acc,
 
 // Camera ray of output pixel (x, packed row r): scene.rs:125-141 + trs.rs:275-284 + ray.rs:74-91
 __device__ __forceinline__ DRay camera_ray(const FrameParams& fp, uint32_t x, uint32_t y) {
-  const float xx = (2.0f * (((float)x + fp.sub_x) * fp.inv_width) - 1.0f) * fp.angle * fp.aspect;
-  const float yy = (1.0f - 2.0f * (((float)y + fp.sub_y) * fp.inv_height)) * fp.angle;
+  const float xx = (2.0f * ((((float)x + fp.sub_step_x) + fp.sub_offset) * fp.inv_width) - 1.0f) * fp.angle * fp.aspect;
+  const float yy = (1.0f - 2.0f * ((((float)y + fp.sub_step_y) + fp.sub_offset) * fp.inv_height)) * fp.angle;
   F4 dir = normalized(vec3(xx, yy, -1.0f));
   F4 origin = point3(0.0f, 0.0f, 0.0f);
   // Ray::scale
