@@ -224,7 +224,8 @@ constexpr uint32_t kTerminated = 0x7FFFFFFFu;  // "no node left": an inner index
 template <bool SPILL>
 struct NodeStack {
   uint32_t* lds;
-  uint32_t* ovf;
+  uint32_t* ovf;       // wave-uniform base of the spill area (a per-lane pointer would be two more registers in every loop)
+  uint32_t gthread;    // this lane's column in it
   uint32_t lds_entries, ovf_stride, sp;
   // the newest entry lives in a register: a pop hands it out at once and fetches its successor from LDS behind
   // the node load that follows, instead of in front of it (-3 % on 5-deep paths, neutral on camera rays)
@@ -232,10 +233,10 @@ struct NodeStack {
   __device__ __forceinline__ void clear() { sp = 0; top = kTerminated; }
   __device__ __forceinline__ void put(uint32_t i, uint32_t v) {
     if (!SPILL || i < lds_entries) lds[i * kBlock] = v;
-    else ovf[(size_t)(i - lds_entries) * ovf_stride] = v;
+    else ovf[(size_t)(i - lds_entries) * ovf_stride + gthread] = v;
   }
   __device__ __forceinline__ uint32_t get(uint32_t i) const {
-    return (!SPILL || i < lds_entries) ? lds[i * kBlock] : ovf[(size_t)(i - lds_entries) * ovf_stride];
+    return (!SPILL || i < lds_entries) ? lds[i * kBlock] : ovf[(size_t)(i - lds_entries) * ovf_stride + gthread];
   }
   __device__ __forceinline__ void push(uint32_t v) {
     if (top != kTerminated) put(sp++, top);
@@ -252,7 +253,8 @@ template <bool SPILL>
 __device__ __forceinline__ NodeStack<SPILL> make_stack(uint32_t* lds_base, const TraceLaunch& tl, uint32_t global_thread) {
   NodeStack<SPILL> st;
   st.lds = lds_base + threadIdx.x;
-  st.ovf = tl.ovf ? tl.ovf + global_thread : nullptr;
+  st.ovf = tl.ovf;
+  st.gthread = global_thread;
   st.lds_entries = tl.lds_entries;
   st.ovf_stride = tl.ovf_stride;
   st.clear();
@@ -511,6 +513,37 @@ struct ShadeCtx {
   float roughness, shininess;
   uint32_t kind;                        // RAYCA_MATERIAL_*
 };
+
+// The path kernel keeps a vertex's ShadeCtx in LDS while its shadow rays are traversed (RAYCA_PARK_CTX): the struct is 27
+// registers that would otherwise have to survive the traversal loop, which at the 128 VGPRs of four waves per SIMD the
+// compiler could only do through scratch (54 spilled VGPRs, 219 MB of scratch writes per 1080p frame).  So do the pending
+// sample's contribution and the running sum of direct light (quads 5 and 6).  Seven float4 per lane, quantity-major (lane i of quantity q at [q * kBlock + i]): a wave's ds_read_b128 / ds_write_b128 touch 64
+// consecutive 16-B slots, the conflict-free shape.  next_origin and the w lanes are recomputed (same operations, same bits).
+#ifndef RAYCA_PARK_CTX
+#define RAYCA_PARK_CTX 1
+#endif
+constexpr uint32_t kCtxQuads = 7;  // ShadeCtx (5) + the pending NEE sample's contribution + the running direct sum
+__device__ __forceinline__ void park_ctx(float4* slot, const ShadeCtx& c) {
+  slot[0 * kBlock] = make_float4(c.point.x, c.point.y, c.point.z, c.roughness);
+  slot[1 * kBlock] = make_float4(c.normal.x, c.normal.y, c.normal.z, c.shininess);
+  slot[2 * kBlock] = make_float4(c.view.x, c.view.y, c.view.z, __uint_as_float(c.kind));
+  slot[3 * kBlock] = make_float4(c.kd.r, c.kd.g, c.kd.b, c.kd.a);
+  slot[4 * kBlock] = make_float4(c.ks.r, c.ks.g, c.ks.b, c.ks.a);
+}
+__device__ __forceinline__ ShadeCtx unpark_ctx(const float4* slot) {
+  const float4 q0 = slot[0 * kBlock], q1 = slot[1 * kBlock], q2 = slot[2 * kBlock], q3 = slot[3 * kBlock], q4 = slot[4 * kBlock];
+  ShadeCtx c;
+  c.point = f4(q0.x, q0.y, q0.z, 1.0f);   // Hit.point is a Point3
+  c.normal = vec3(q1.x, q1.y, q1.z);
+  c.view = vec3(q2.x, q2.y, q2.z);
+  c.next_origin = c.point + c.normal * kRayBias;  // hit.rs:164-171, as in shade_hit
+  c.kd = Color{q3.x, q3.y, q3.z, q3.w};
+  c.ks = Color{q4.x, q4.y, q4.z, q4.w};
+  c.roughness = q0.w;
+  c.shininess = q1.w;
+  c.kind = __float_as_uint(q2.w);
+  return c;
+}
 
 // get_color (primitive.rs:142-148) always; the rest only when `full` (Pathtracer).
 // barycentrics: u -> vertex 0, v -> vertex 1, 1-u-v -> vertex 2 (bvh/triangle.rs:34-38)
@@ -827,6 +860,9 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
                                                        TraceCounters* counters, TraceLaunch tl) {
   extern __shared__ uint32_t lds_stack[];
   NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
+  // behind the stack rows: this lane's parked ShadeCtx (path frames only; the host sizes the allocation)
+  float4* const ctx_slot = reinterpret_cast<float4*>(lds_stack + tl.lds_entries * kBlock) + threadIdx.x;
+  constexpr bool PARK = RAYCA_PARK_CTX && MODE == kModePath;
   const uint32_t lane = __lane_id();
   const uint32_t home = xcc_id();
   WorkCursor wc;
@@ -863,20 +899,21 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
       }
     }
     const size_t slot = (size_t)depth * pb.npix + p;
-    bool want_bounce = false;
-    QueuedRay next{};
     bool in_shadow = false;
+    // shadow rays: the any-hit bound.  A point light's is its distance (a finite square root, never FLT_MAX); FLT_MAX
+    // means "closest hit wanted": camera and bounce rays, and the shadow ray of a quad light (NeeSample.quad)
     float t_stop = FLT_MAX;
     ShadeCtx cx;
-    NeeSample ns;
-    ns.x = black();
-    ns.t_stop = FLT_MAX;
-    ns.quad = 0u;
-    Color direct = black();
+    Color ns_x = black();  // the pending NEE sample's contribution if its light turns out to be visible   (PARK: quad 5)
+    Color direct = black();  // sum of the direct samples so far                                           (PARK: quad 6)
     uint32_t li = 0, k = 0, dim = 0;
     // FUSED (Flat only): a lane that finishes leaves its pixel sum in `direct`; the gamma + quantise + store tail runs
     // once per batch with the wave reconverged, not inside the divergent state machine
     const bool has_pixel = live;
+    // Path: a vertex whose direct samples are all in leaves the loop with `tail` set; its record, the bounce sample and the
+    // next generation's ray are made behind the loop, with the wave reconverged -- so the bounce ray is not a loop-carried
+    // value (eight registers the traversal loop had to carry for nothing) and the sampling code runs with full lanes
+    bool tail = false;
 
     while (live) {
       DHit hit;
@@ -904,21 +941,30 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
             live = false;
           } else {
             in_shadow = true;  // enter the NEE loop (possibly empty)
+            if (PARK) {
+              park_ctx(ctx_slot, cx);
+              ctx_slot[6 * kBlock] = as_f4(black());
+            }
           }
         }
       } else {
         // outcome of the pending NEE sample
         bool lit;
-        if (ns.quad) {
+        if (t_stop == FLT_MAX) {  // quad light: "lit iff the closest hit is emissive" (nee.rs:103-104)
           lit = false;
           if (found) {
             const uint32_t hm = sc.ext[hit.prim].material;
             lit = hm != RAYCA_NONE && hm < sc.material_count && sc.materials[hm].emissive != 0u;
           }
         } else {
-          lit = !(found && hit.t < ns.t_stop);  // nee.rs:152-156
+          lit = !(found && hit.t < t_stop);  // nee.rs:152-156
         }
-        direct = direct + (lit ? ns.x : black());
+        if (PARK) {
+          const Color sum = as_color(ctx_slot[6 * kBlock]) + (lit ? as_color(ctx_slot[5 * kBlock]) : black());
+          ctx_slot[6 * kBlock] = as_f4(sum);
+        } else {
+          direct = direct + (lit ? ns_x : black());
+        }
         if (++k == fp.light_samples) {
           k = 0;
           ++li;
@@ -926,46 +972,13 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
       }
       if (live && in_shadow) {
         if (li < nee_lights) {
-          ns = nee_prepare(sc, fp, cx, li, k, key, dim, ray);
+          if (PARK) cx = unpark_ctx(ctx_slot);  // (its own LDS slot: no barrier; the compiler orders a lane's LDS accesses)
+          const NeeSample ns = nee_prepare(sc, fp, cx, li, k, key, dim, ray);
+          if (PARK) ctx_slot[5 * kBlock] = as_f4(ns.x);
+          else ns_x = ns.x;
           t_stop = ns.t_stop;
-          n_shadow++;
         } else {
-          // all direct samples done: Pathtracer::trace_impl tail  pathtracer.rs:89-105
-          const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
-          pb.direct[slot] = as_f4(direct);
-          if (depth < limit) {
-            // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40
-            const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
-            const bool hemi = fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE;
-            const float theta = hemi ? acosf(e1) : acosf(sqrtf(e1));
-            const float omega_a = 2.0f * kPi * e2;
-            const F4 sdir = vec3(cosf(omega_a) * sinf(theta), sinf(omega_a) * sinf(theta), cosf(theta));
-            const F4 w = cx.normal;
-            const F4 a = close(w, vec3(0, 1, 0)) ? vec3(1, 0, 0) : vec3(0, 1, 0);
-            const F4 u = normalized(cross(a, w));
-            F4 v = cross(w, u);
-            if (hemi) v = normalized(v);
-            const F4 omega_i = (sdir.x * u + sdir.y * v) + sdir.z * w;
-            const Color brdf = surf_brdf(cx, omega_i);
-            // the factor SoftSampler::get_radiance applies to the incoming radiance, evaluated in its
-            // order up to the point where the child's result enters: cosine.rs:90-99 `PI * brdf`,
-            // hemisphere.rs:42-52 `2.0 * PI * brdf * cosine_law`
-            Color factor;
-            if (hemi) factor = ((2.0f * kPi) * brdf) * clampf(dot(cx.normal, omega_i), 0.0f, 1.0f);
-            else factor = kPi * brdf;
-            pb.brdf[slot] = as_f4(factor);
-            pb.state[slot] = kVertexLit;
-            if (depth + 1u < fp.max_depth) {
-              want_bounce = true;
-              next.ox = cx.next_origin.x; next.oy = cx.next_origin.y; next.oz = cx.next_origin.z;
-              next.dx = omega_i.x; next.dy = omega_i.y; next.dz = omega_i.z;
-              next.pixel = p;
-              next.key = rng_child(key, 0u);
-              n_bounce++;
-            }
-          } else {
-            pb.state[slot] = kVertexLitNoIndirect;
-          }
+          tail = true;
           live = false;
         }
       }
@@ -973,6 +986,53 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
     if (FUSED) {
       if (has_pixel) finalize_pixel(fp, direct, p, rgba8, rgba32f);
     } else if (MODE == kModePath) {
+      bool want_bounce = false;
+      QueuedRay next{};
+      if (tail) {
+        // all direct samples done: Pathtracer::trace_impl tail  pathtracer.rs:89-105
+        if (PARK) {
+          cx = unpark_ctx(ctx_slot);
+          direct = as_color(ctx_slot[6 * kBlock]);
+        }
+        const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
+        pb.direct[slot] = as_f4(direct);
+        if (depth < limit) {
+          // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40
+          const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
+          const bool hemi = fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE;
+          const float theta = hemi ? acosf(e1) : acosf(sqrtf(e1));
+          const float omega_a = 2.0f * kPi * e2;
+          const F4 sdir = vec3(cosf(omega_a) * sinf(theta), sinf(omega_a) * sinf(theta), cosf(theta));
+          const F4 w = cx.normal;
+          const F4 a = close(w, vec3(0, 1, 0)) ? vec3(1, 0, 0) : vec3(0, 1, 0);
+          const F4 u = normalized(cross(a, w));
+          F4 v = cross(w, u);
+          if (hemi) v = normalized(v);
+          const F4 omega_i = (sdir.x * u + sdir.y * v) + sdir.z * w;
+          const Color brdf = surf_brdf(cx, omega_i);
+          // the factor SoftSampler::get_radiance applies to the incoming radiance, evaluated in its
+          // order up to the point where the child's result enters: cosine.rs:90-99 `PI * brdf`,
+          // hemisphere.rs:42-52 `2.0 * PI * brdf * cosine_law`
+          Color factor;
+          if (hemi) factor = ((2.0f * kPi) * brdf) * clampf(dot(cx.normal, omega_i), 0.0f, 1.0f);
+          else factor = kPi * brdf;
+          pb.brdf[slot] = as_f4(factor);
+          pb.state[slot] = kVertexLit;
+          if (depth + 1u < fp.max_depth) {
+            want_bounce = true;
+            next.ox = cx.next_origin.x; next.oy = cx.next_origin.y; next.oz = cx.next_origin.z;
+            next.dx = omega_i.x; next.dy = omega_i.y; next.dz = omega_i.z;
+            next.pixel = p;
+            next.key = rng_child(key, 0u);
+          }
+        } else {
+          pb.state[slot] = kVertexLitNoIndirect;
+        }
+      }
+      // ray counts, wave-uniform (per-lane counters would be loop-carried registers of the traversal loop): every vertex
+      // that reaches `tail` has traced all of its nee_lights x light_samples shadow rays
+      n_shadow += (uint32_t)__popcll(__ballot(tail)) * nee_lights * fp.light_samples;
+      n_bounce += (uint32_t)__popcll(__ballot(want_bounce));
       push_ray(want_bounce, next, out_rays, out_count);
     }
   }
@@ -995,11 +1055,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
     }
   }
   if (MODE == kModePath) {
-    unsigned long long s2 = n_shadow, b2 = n_bounce;
-    for (int off = 32; off > 0; off >>= 1) {
-      s2 += __shfl_down(s2, off);
-      b2 += __shfl_down(b2, off);
-    }
+    const unsigned long long s2 = n_shadow, b2 = n_bounce;  // already whole-wave sums
     if (lane == 0 && (s2 | b2)) {
       atomicAdd(&counters->shadow, s2);
       atomicAdd(&counters->bounce, b2);
