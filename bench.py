@@ -266,7 +266,7 @@ def main():
     for _ in range(20):
         st0 = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
         node_format = st0["node_format"]
-        if not node_format & 256:
+        if not node_format & (256 | 512):   # 256: still timing node formats, 512: still timing the camera-ray kernels
             break
     for i in range(1, F):   # first use of a frame context allocates its work buffers: not inside the timed region
         ds.render_device(cfg, W, H, outs[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i)
@@ -337,7 +337,8 @@ def main():
                    "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
                    "node_format": {"generation0": ("4-wide" if node_format & 1 else "binary") + (" fp16" if node_format & 4 else " f32"),
                                    "bounces": ("4-wide" if node_format & 2 else "binary") + (" fp16" if node_format & 8 else " f32"),
-                                   "chosen_by": "timing the four formats on this scene (same pixels with each)"},
+                                   "camera_rays": "lane-refill kernel (refill.hip)" if node_format & 1024 else "generation kernel",
+                                   "chosen_by": "timing the four formats, then the two camera-ray kernels, on this scene (same pixels with each)"},
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",

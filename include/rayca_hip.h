@@ -285,6 +285,14 @@ enum {
   RAYCA_ENGINE_FUSED = 3
 };
 
+enum {
+  /* camera rays of a one-sample Flat frame on a RAYCA_BUILDER_SAH scene: the scene times both kernels on its first
+   * large frames and keeps the faster (same bits) */
+  RAYCA_CAMERA_AUTO = 0,
+  RAYCA_CAMERA_GENERATION = 1, /* the fused generation kernel: a wave keeps its 64 rays until the slowest has finished */
+  RAYCA_CAMERA_REFILL = 2      /* lane refill (refill.hip): finished lanes take new pixels while long rays keep theirs */
+};
+
 typedef struct RaycaBuildOptions {
   uint32_t builder;   /* RAYCA_BUILDER_* */
   uint32_t device;    /* HIP device ordinal */
@@ -314,7 +322,8 @@ typedef struct RaycaRenderOptions {
    * different contexts (and different streams) may be in flight at the same time; calls that use the same
    * context are serialised.  The scene (BVH, triangles, materials) is shared. */
   uint32_t context;
-  uint32_t reserved[2];
+  uint32_t camera_rays;   /* RAYCA_CAMERA_* */
+  uint32_t reserved;
 } RaycaRenderOptions;
 
 /* Filled by every render call (all counters are per call, summed over spp and generations). */
@@ -338,7 +347,9 @@ typedef struct RaycaStats {
   uint32_t rows_rendered;
   /* node format of this frame's launches: bit 0 = generation 0 used 4-wide nodes, bit 1 = the bounce
    * generations did, bits 2 / 3 = the same for fp16 node boxes, bit 8 = this was a calibration frame (the scene
-   * is still timing the formats) */
+   * is still timing the formats), bit 9 = a calibration frame of the camera-ray kernel choice (Flat frames: fused
+   * generation kernel or lane-refill kernel, timed once the format is settled), bit 10 = this frame's camera rays ran on
+   * the lane-refill kernel */
   uint32_t node_format;
 } RaycaStats;
 

@@ -36,7 +36,7 @@ COLOR_RGB8, COLOR_RGBA8, COLOR_RGBA32F = 0, 1, 2
 BUILDER_REFERENCE, BUILDER_SAH = 0, 1
 ENGINE_AUTO, ENGINE_GENERAL, ENGINE_WAVEFRONT, ENGINE_FUSED = 0, 1, 2, 3
 TRAVERSAL_ORDERED, TRAVERSAL_EXHAUSTIVE = 0, 1
-ENGINE_AUTO, ENGINE_GENERAL, ENGINE_WAVEFRONT, ENGINE_FUSED = 0, 1, 2, 3
+CAMERA_AUTO, CAMERA_GENERATION, CAMERA_REFILL = 0, 1, 2
 
 
 class RaycaConfig(C.Structure):
@@ -191,7 +191,8 @@ class RaycaRenderOptions(C.Structure):
         ("stream", C.c_void_p),
         ("engine", C.c_uint32),
         ("context", C.c_uint32),
-        ("reserved", C.c_uint32 * 2),
+        ("camera_rays", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

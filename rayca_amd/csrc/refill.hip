@@ -1,0 +1,198 @@
+// refill.hip -- camera rays of a Flat frame with LANE REFILL (gfx950).
+//
+// k_generation gives a wave 64 rays and keeps it until the slowest of them has finished.  Where the length of a ray's
+// walk through the tree varies a lot inside a tile -- the 1 M-triangle soup: free paths through a random cloud are
+// exponentially distributed, so the longest of 64 is about 4.7 times the mean -- most lanes of a wave idle most of the
+// time (measured: 17 % lane utilisation in the node loop, 21.5 % of VALU thread-cycles active).  Here a wave is a
+// persistent pool of 64 lanes: when no more than RAYCA_REFILL_THRESHOLD of them are still traversing, the finished
+// ones shade and store their pixel (Flat::trace, integrator/flat.rs:16-28; scene.rs:146-148) and take new pixels from
+// the wave's current 8x8 tile (work tickets as in k_generation: one counter per XCD), while the long rays keep their
+// place.  Same arithmetic, same node_step / test_leaf / shade_hit as every other kernel (trace_core.inc): the frame is
+// bit-identical to k_generation's (tests/test_gpu_engines.py); which of the two renders a scene's Flat frames is decided
+// by timing both on that scene (RaycaScene::Tune in api.inc).
+//
+// Coherent scenes lose with it (the atrium's camera rays: new rays at the root next to old rays deep in the tree
+// diverge in their node addresses), which is why it is a per-scene choice and not the default.
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+#include "refill.hpp"
+
+namespace rayca {
+namespace {
+
+#include "trace_core.inc"
+
+#ifndef RAYCA_REFILL_THRESHOLD
+#define RAYCA_REFILL_THRESHOLD 44
+#endif
+#ifndef RAYCA_REFILL_SCHED
+#define RAYCA_REFILL_SCHED 0
+#endif
+#ifndef RAYCA_REFILL_LEAVE_K
+#define RAYCA_REFILL_LEAVE_K 32
+#endif
+#ifndef RAYCA_REFILL_WAVES
+#define RAYCA_REFILL_WAVES RAYCA_MIN_WAVES_FLAT
+#endif
+#ifndef RAYCA_REFILL_NODE_W
+#define RAYCA_REFILL_NODE_W 1
+#endif
+#ifndef RAYCA_REFILL_LEAF_W
+#define RAYCA_REFILL_LEAF_W 1
+#endif
+
+template <bool SPH, bool WIDE, bool SPILL, bool STATS, bool HALF>
+__global__ __launch_bounds__(kBlock, RAYCA_REFILL_WAVES) void k_flat_refill(DevScene sc, FrameParams fp, uint32_t* heads, uint8_t* rgba8, float4* rgba32f,
+                                                                             TraceCounters* counters, TraceLaunch tl) {
+  extern __shared__ uint32_t lds_stack[];
+  NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
+  const uint32_t lane = __lane_id();
+  const uint32_t home = xcc_id();
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  WorkCursor wc;
+  LaneCounters cnt;
+  uint32_t n_shaded = 0;
+  // lane state: a ray that is still traversing (cur != kTerminated), a finished ray waiting to be retired (has), or nothing
+  bool has = false;
+  uint32_t cur = kTerminated, p = 0;
+  DRay ray{};
+  FastRay fr{};
+  DHit hit{};
+  float limit = INFINITY;
+  // wave state: pixels [pool_next, pool_end) of the tile list (64 per tile, in tile order) not handed out yet
+  uint32_t pool_next = 0, pool_end = 0;
+  bool dry = false;  // the work counters are exhausted
+
+  for (;;) {
+    const uint32_t n_active = (uint32_t)__popcll(__ballot(cur != kTerminated));
+    if (n_active <= (dry ? 0u : (uint32_t)RAYCA_REFILL_THRESHOLD)) {
+      if (has && cur == kTerminated) {  // retire: Flat::trace + the pixel store
+        Color sum = black() + black();  // unwrap_or(BLACK), color += it
+        if (hit.prim != RAYCA_NONE) {
+          n_shaded++;
+          Color color;
+          bool emissive;
+          ShadeCtx unused;
+          shade_hit<SPH>(sc, ray, hit, false, color, emissive, unused);
+          sum = black() + color;
+        }
+        finalize_pixel(fp, sum, p, rgba8, rgba32f);
+        has = false;
+      }
+      if (dry && n_active == 0u) break;  // every lane reaches this: n_active and dry are wave-uniform
+      while (!dry) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle == 0ull) break;
+        if (pool_next == pool_end) {
+          const uint32_t batch = next_batch(heads, fp.tile_count, home, wc, tl.ticket);
+          if (batch == RAYCA_NONE) {
+            dry = true;
+            break;
+          }
+          pool_next = batch * 64u;
+          pool_end = pool_next + 64u;
+        }
+        const uint32_t avail = pool_end - pool_next;
+        const uint32_t rank = (uint32_t)__popcll(idle & lanes_below);
+        if (!has && rank < avail) {
+          const uint32_t idx = pool_next + rank, batch = idx >> 6, l = idx & 63u;
+          const uint32_t ty = batch / fp.tiles_x, tx = batch - ty * fp.tiles_x;
+          const uint32_t x = tx * kTileW + (l & (kTileW - 1u)), r = ty * kTileH + (l >> RAYCA_TILE_W_LOG2);
+          if (x < fp.width && r < fp.rows) {  // (pixels of a ragged edge tile outside the frame are skipped: the lane asks again)
+            const uint32_t y = ((r / fp.band) * fp.parts + fp.part) * fp.band + (r % fp.band);
+            p = r * fp.width + x;
+            ray = camera_ray(fp, x, y);
+            // prologue of trace(): Tlas::intersects tests the root box first (blas.rs:136-139)
+            fr = make_fast(sc, ray, HALF);
+            hit.t = INFINITY;
+            hit.prim = RAYCA_NONE;
+            hit.u = hit.v = 0.0f;
+            limit = INFINITY;
+            stack.clear();
+            float tmin;
+            if (STATS) cnt.boxes++;
+            cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin)
+                      ? (WIDE ? sc.root_ref4 : sc.root_ref)
+                      : kTerminated;
+            has = true;
+          }
+        }
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        pool_next += n_idle < avail ? n_idle : avail;
+      }
+    }
+    // One trip of the traversal for the lanes that hold a ray: EITHER a node step for the lanes that are searching (cur is an
+    // inner node) OR the leaf test for the lanes that hold a leaf -- whichever side has more lanes (weighted:
+    // RAYCA_REFILL_NODE_W searching lanes count like RAYCA_REFILL_LEAF_W leaf lanes).  trace()'s while-while form keeps
+    // stepping until the slowest search of the wave has found its leaf; with refilled lanes descending from the root next
+    // to lanes deep in the tree that idles most of the wave (measured on the soup: 0.29 lane utilisation in the node loop,
+    // 9.5 ms per frame; with the majority rule 0.6-0.7 in both loops).  Every lane still performs its own steps in its own
+    // order: only the interleaving of lanes changes, not a single result.
+#if RAYCA_REFILL_SCHED == 1
+    const bool searching = !(cur & kLeafFlag) && cur != kTerminated;
+    const bool at_leaf = (cur & kLeafFlag) != 0u;
+    const uint32_t n_search = (uint32_t)__popcll(__ballot(searching)), n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+    if (n_search * (uint32_t)RAYCA_REFILL_NODE_W >= n_leaf * (uint32_t)RAYCA_REFILL_LEAF_W && n_search != 0u) {
+      if (searching) cur = node_step<true, true, WIDE, SPILL, STATS, HALF>(sc, ray, fr, limit, cur, stack, cnt);
+    } else if (at_leaf) {
+      test_leaf<true, SPH, STATS>(sc, ray, cur, FLT_MAX, hit, limit, cnt);
+      cur = stack.pop();
+    }
+#else
+    // RAYCA_REFILL_SCHED 0: node phase until fewer than RAYCA_REFILL_LEAVE_K lanes are still searching (and some lane holds
+    // a leaf), then the leaf phase for every lane that holds one
+    for (;;) {
+      const bool searching = !(cur & kLeafFlag) && cur != kTerminated;
+      const uint32_t n = (uint32_t)__popcll(__ballot(searching));
+      if (n == 0u) break;
+      if (n < (uint32_t)RAYCA_REFILL_LEAVE_K && __ballot((cur & kLeafFlag) != 0u) != 0ull) break;
+      if (searching) cur = node_step<true, true, WIDE, SPILL, STATS, HALF>(sc, ray, fr, limit, cur, stack, cnt);
+    }
+    if (cur & kLeafFlag) {
+      test_leaf<true, SPH, STATS>(sc, ray, cur, FLT_MAX, hit, limit, cnt);
+      cur = stack.pop();
+    }
+#endif
+  }
+  if (STATS) {
+    unsigned long long b = cnt.boxes, t = cnt.tris, sh = n_shaded, sb = cnt.slot_boxes, stt = cnt.slot_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off);
+      t += __shfl_down(t, off);
+      sh += __shfl_down(sh, off);
+      sb += __shfl_down(sb, off);
+      stt += __shfl_down(stt, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&counters->boxes, b);
+      atomicAdd(&counters->tris, t);
+      atomicAdd(&counters->shaded, sh);
+      atomicAdd(&counters->box_slots, sb);
+      atomicAdd(&counters->tri_slots, stt);
+    }
+  }
+}
+
+using RefillKernel = void (*)(DevScene, FrameParams, uint32_t*, uint8_t*, float4*, TraceCounters*, TraceLaunch);
+template <bool SPH, bool STATS>
+RefillKernel pick2(bool wide, bool spill, bool half) {
+  if (wide) return half ? k_flat_refill<SPH, true, true, STATS, true> : k_flat_refill<SPH, true, true, STATS, false>;  // 4-wide: always with the spill path
+  if (spill) return half ? k_flat_refill<SPH, false, true, STATS, true> : k_flat_refill<SPH, false, true, STATS, false>;
+  return half ? k_flat_refill<SPH, false, false, STATS, true> : k_flat_refill<SPH, false, false, STATS, false>;
+}
+RefillKernel pick(const RefillFlavour& f) {
+  if (f.sph) return f.stats ? pick2<true, true>(f.wide, f.spill, f.half) : pick2<true, false>(f.wide, f.spill, f.half);
+  return f.stats ? pick2<false, true>(f.wide, f.spill, f.half) : pick2<false, false>(f.wide, f.spill, f.half);
+}
+
+}  // namespace
+
+const void* flat_refill_kernel(const RefillFlavour& f) { return reinterpret_cast<const void*>(pick(f)); }
+
+void launch_flat_refill(const RefillFlavour& f, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const FrameParams& fp, uint32_t* heads,
+                        uint8_t* rgba8, float4* rgba32f, TraceCounters* counters, const TraceLaunch& tl) {
+  hipLaunchKernelGGL(pick(f), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, fp, heads, rgba8, rgba32f, counters, tl);
+}
+
+}  // namespace rayca

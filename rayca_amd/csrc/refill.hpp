@@ -1,0 +1,17 @@
+// refill.hpp -- host-side entry of the lane-refill camera-ray kernel (refill.hip), called from api.inc.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+
+namespace rayca {
+
+struct RefillFlavour {
+  bool sph, wide, spill, stats, half;
+};
+// host stub of the instantiation (for hipFuncGetAttributes) and its launch
+const void* flat_refill_kernel(const RefillFlavour& f);
+void launch_flat_refill(const RefillFlavour& f, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const FrameParams& fp, uint32_t* heads,
+                        uint8_t* rgba8, float4* rgba32f, TraceCounters* counters, const TraceLaunch& tl);
+
+}  // namespace rayca

@@ -78,10 +78,10 @@ class DeviceScene:
         return out
 
     @staticmethod
-    def _opts(traversal, collect_stats, tile, stream, engine=abi.ENGINE_AUTO, context=0):
+    def _opts(traversal, collect_stats, tile, stream, engine=abi.ENGINE_AUTO, context=0, camera_rays=abi.CAMERA_AUTO):
         o = abi.RaycaRenderOptions()
         o.traversal, o.collect_stats = traversal, int(collect_stats)
-        o.engine, o.context = engine, context
+        o.engine, o.context, o.camera_rays = engine, context, camera_rays
         if tile is not None:
             o.tile.part, o.tile.parts, o.tile.band_rows = tile
         o.stream = stream
@@ -93,14 +93,15 @@ class DeviceScene:
         return self._lib.rayca_hip_tile_rows(C.byref(t), height)
 
     def render(self, config: Config, width: int, height: int, *, traversal=abi.TRAVERSAL_ORDERED,
-               collect_stats=False, tile=None, want_rgba8=True, want_f32=True, engine=abi.ENGINE_AUTO, context=0):
+               collect_stats=False, tile=None, want_rgba8=True, want_f32=True, engine=abi.ENGINE_AUTO, context=0,
+               camera_rays=abi.CAMERA_AUTO):
         """rayca_hip_render: host outputs. Returns (rgba8 | None, rgba32f | None, stats dict)."""
         rows = height if tile is None else self.tile_rows(tile, height)
         u8 = np.zeros((rows, width, 4), np.uint8) if want_rgba8 else None
         f32 = np.zeros((rows, width, 4), np.float32) if want_f32 else None
         st = abi.RaycaStats()
         cfg = config.to_abi()
-        o = self._opts(traversal, collect_stats, tile, None, engine, context)
+        o = self._opts(traversal, collect_stats, tile, None, engine, context, camera_rays)
         lib.check(self._lib.rayca_hip_render(self.handle, C.byref(cfg), width, height, C.byref(o),
                                              u8.ctypes.data if u8 is not None else None,
                                              f32.ctypes.data if f32 is not None else None, C.byref(st)))
@@ -108,11 +109,11 @@ class DeviceScene:
 
     def render_device(self, config: Config, width: int, height: int, d_rgba8: int, d_f32: int = 0, *,
                       traversal=abi.TRAVERSAL_ORDERED, collect_stats=False, tile=None, stream=None,
-                      want_stats=False, engine=abi.ENGINE_AUTO, context=0):
+                      want_stats=False, engine=abi.ENGINE_AUTO, context=0, camera_rays=abi.CAMERA_AUTO):
         """rayca_hip_render_device: outputs stay in device memory (pointers as ints)."""
         st = abi.RaycaStats()
         cfg = config.to_abi()
-        o = self._opts(traversal, collect_stats, tile, stream, engine, context)
+        o = self._opts(traversal, collect_stats, tile, stream, engine, context, camera_rays)
         lib.check(self._lib.rayca_hip_render_device(self.handle, C.byref(cfg), width, height, C.byref(o),
                                                     d_rgba8 or None, d_f32 or None,
                                                     C.byref(st) if want_stats else None))

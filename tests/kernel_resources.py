@@ -1,11 +1,13 @@
 """Register / spill / scratch / LDS figures of every kernel, read from the gfx950 code object's metadata.
-usage: python tests/kernel_resources.py [extra hipcc flags ...]   (compiles rayca_amd/csrc/kernels.hip device-only into /tmp)"""
+usage: python tests/kernel_resources.py [extra hipcc flags ...]   (compiles rayca_amd/csrc/kernels.hip device-only into /tmp;
+RAYCA_KRES_UNIT=refill|bvh_build picks another translation unit)"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 out = "/tmp/rayca_kernels_dev.o"
-src = os.path.join(g.CSRC, "kernels.hip")
+src = os.path.join(g.CSRC, os.environ.get("RAYCA_KRES_UNIT", "kernels") + ".hip")
+out = f"/tmp/rayca_{os.environ.get('RAYCA_KRES_UNIT', 'kernels')}_dev.o"
 if not os.environ.get("RAYCA_KRES_REUSE"):
     subprocess.run([g.HIPCC, "--offload-arch=gfx950", "--cuda-device-only", *g.COMMON, *sys.argv[1:], "-c", src, "-o", out], check=True)
 co = out + ".co"   # the device-only object is still an offload bundle: take the gfx950 code object out of it

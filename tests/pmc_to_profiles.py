@@ -30,4 +30,14 @@ for wl in ("atrium", "soup"):
         "L1_hit_rate": 1.0 - g["TCP_TCC_READ_REQ_sum"] / g["TCP_TOTAL_CACHE_ACCESSES_sum"],
         "valu_busy": 4.0 * g["SQ_INSTS_VALU"] / (1024.0 * g["GRBM_GUI_ACTIVE"] / 8.0),
     }, open(os.path.join(out, f"pmc_traffic_{wl}.json"), "w"), indent=1)
+    # everything bench.py needs to price the kernel against VALU issue, L1, L2 and HBM limits, per launch
+    keys = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum",
+            "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT")
+    json.dump({
+        "workload": wl, "kernel": "k_generation (generation 0)", "session": tag,
+        "source": "rocprofv3 --pmc, separate passes (tests/pmc_passes.sh): mean over the dispatches of tests/profile_run.py, node format pinned to the one bench.py reports",
+        "units": "FETCH_SIZE / WRITE_SIZE in KiB (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2, MI355X_MICROARCH.md HBM section); all others are event counts summed over the chip",
+        "counters_per_launch": {k: g[k] for k in keys if k in g},
+    }, open(os.path.join(out, f"pmc_counters_{wl}.json"), "w"), indent=1)
     print(wl, "traffic", traffic)

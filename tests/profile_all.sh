@@ -3,7 +3,7 @@
 # duration is the kernel's own; and with the default frames in flight), then PMC passes for atrium and soup.
 # Summaries land under gpurun_out/; tests/pmc_to_profiles.py copies the judged ones into profiles/.
 export TMPDIR=/tmp
-sfx=${1:-9}
+sfx=${1:-r02}
 mkdir -p gpurun_out/prof$sfx &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof$sfx/atrium -- python3 bench.py --steps 20 --warmup 3 --frames-in-flight 1 > gpurun_out/prof$sfx/bench_atrium.json 2> gpurun_out/prof$sfx/bench_atrium.err &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof$sfx/atrium_f3 -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof$sfx/bench_atrium_f3.json 2> gpurun_out/prof$sfx/bench_atrium_f3.err &&

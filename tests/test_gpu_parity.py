@@ -443,6 +443,18 @@ def test_config3_soup_4096_full_size(gpu):
         else:
             assert np.array_equal(u8, first), (i, st["node_format"])
     assert formats == {0, 1, 4, 5} and not st["node_format"] & 256   # all four were used; the ninth frame is past calibration
+    # frames 9..12 time the two camera-ray kernels (fused generation kernel / lane refill) on the chosen format: same frame
+    kernels = {bool(st["node_format"] & 1024)}
+    assert st["node_format"] & 512
+    for i in range(3):
+        u8, _, st = ds.render(FLAT, w, h, want_f32=False)
+        assert st["node_format"] & 512 and np.array_equal(u8, first), (i, st["node_format"])
+        kernels.add(bool(st["node_format"] & 1024))
+    assert kernels == {False, True}
+    u8, _, st = ds.render(FLAT, w, h, want_f32=False, collect_stats=True)
+    assert not st["node_format"] & (256 | 512) and np.array_equal(u8, first)
+    print(f"[soup 4096^2] chosen: format bits {st['node_format'] & 5}, lane refill {bool(st['node_format'] & 1024)}, "
+          f"node-loop lane utilisation {st['boxes_tested'] / st['wave_box_slots']:.3f}, leaf loop {st['triangles_tested'] / st['wave_triangle_slots']:.3f}")
     ex, _, _ = ds.render(FLAT, w, h, want_f32=False, traversal=abi.TRAVERSAL_EXHAUSTIVE)
     assert np.array_equal(ex, first)
     hit = (first[..., :3].astype(np.int32).sum(-1) > 0).mean()
