@@ -4,7 +4,10 @@
 //   host_mirror describe <scene> <out_dir>     flatten only, dump every array of the RaycaSceneDesc (no GPU)
 //   host_mirror draw <scene> <out.rgba> [png]  SoftRenderer::draw on device 0, raw RGBA8 (+ PNG)
 //   host_mirror png <in.png> <out_dir>         decode a PNG with the loader's decoder, dump w/h/type + texels
+//   host_mirror sdtf_config <in.sdtf> <out_dir>  load an SDTF file, dump its SdtfConfig and the Config after Config::apply
 // scene "gltf:<path>" = rayca-soft/tests/gltf.rs:191-204 `gltf::cube`: the file + create_default_model()
+// scene "sdtf:<path>" = rayca-soft/tests/sdtf.rs:7-25 `run_test`: Scene::push_sdtf_from_path, nothing else
+// scene "sdtfstr:<text>" = the loader's own unit tests (rayca-model/src/loader/sdtf.rs:913-947): SdtfBuilder::_str
 //
 // tests/test_cpp_host.py compares `describe` with rayca_amd.flatten of the same scene built through the
 // Python mirror, and `draw` with the Python host's frame.
@@ -15,6 +18,7 @@
 
 #include "rayca.hpp"
 #include "rayca_gltf.hpp"
+#include "rayca_sdtf.hpp"
 
 using namespace rayca;
 
@@ -102,8 +106,20 @@ static Scene gltf_scene(const std::string& path) {
   return scene;
 }
 
+static Scene sdtf_scene(const std::string& path) {
+  Scene scene;
+  push_sdtf_from_path(scene, path);
+  return scene;
+}
+
 static Scene make(const std::string& name) {
   if (name.rfind("gltf:", 0) == 0) return gltf_scene(name.substr(5));
+  if (name.rfind("sdtf:", 0) == 0) return sdtf_scene(name.substr(5));
+  if (name.rfind("sdtfstr:", 0) == 0) {
+    Scene scene;
+    scene.push_model(load_sdtf_str(name.substr(8)).first);
+    return scene;
+  }
   if (name == "triangle") return triangle_scene();
   if (name == "sphere") return sphere_scene();
   if (name == "cube") return cube_scene();
@@ -132,6 +148,20 @@ int main(int argc, char** argv) {
       const std::vector<uint32_t> head = {im.w, im.h, (uint32_t)im.color_type};
       dump(out, "png_head", head);
       dump(out, "png_texels", im.data);
+      return 0;
+    }
+    if (mode == "sdtf_config") {
+      const SdtfConfig sc = name.rfind("str:", 0) == 0 ? load_sdtf_str(name.substr(4)).second : load_sdtf_path(name).second;
+      Config cfg = Config::builder().bvh(false).build();   // as rayca-soft/tests/sdtf.rs builds it
+      apply(cfg, sc);
+      float g[2] = {sc.gamma, cfg.gamma};
+      uint32_t gb[2];
+      std::memcpy(gb, g, sizeof gb);
+      const std::vector<int64_t> v = {sc.width, sc.height, sc.max_depth, sc.light_samples, sc.light_stratify, sc.samples_per_pixel, (int64_t)sc.direct_sampler,
+                                      sc.russian_roulette, (int64_t)sc.indirect_sampler, (int64_t)sc.integrator, (int64_t)sc.brdf, gb[0],
+                                      cfg.bvh, cfg.light_samples, cfg.light_stratify, cfg.samples_per_pixel, cfg.russian_roulette, (int64_t)cfg.direct_sampler,
+                                      (int64_t)cfg.indirect_sampler, (int64_t)cfg.integrator, cfg.max_depth, gb[1]};
+      dump(out, "sdtf_config", v);
       return 0;
     }
     const Scene scene = make(name);
