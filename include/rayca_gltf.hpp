@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "rayca.hpp"
+#include "rayca_jpeg.hpp"
 
 namespace rayca {
 namespace gltf_detail {
@@ -317,7 +318,7 @@ inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint3
 // PNG -> Image (RGB8 or RGBA8), like image::ImageReader::decode + Image::load_data (rayca-model/src/image.rs:143-158)
 inline Image decode_png(const std::vector<uint8_t>& f) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-  if (f.size() < 8 || std::memcmp(f.data(), sig, 8)) throw Error(RAYCA_ERR_UNSUPPORTED, "image: only PNG can be decoded without an image library");
+  if (f.size() < 8 || std::memcmp(f.data(), sig, 8)) throw Error(RAYCA_ERR_BAD_ARG, "PNG: bad signature");
   uint32_t w = 0, h = 0;
   int depth = 0, ctype = 0, interlace = 0;
   std::vector<uint8_t> idat, plte, trns;
@@ -381,6 +382,13 @@ inline Image decode_png(const std::vector<uint8_t>& f) {
     }
   }
   return im;
+}
+
+// image::ImageReader::with_guessed_format().decode()  (rayca-model/src/image.rs:143-158): PNG or JPEG, by signature
+inline Image decode_image(const std::vector<uint8_t>& f) {
+  if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) return decode_jpeg(f);
+  if (f.size() >= 8 && f[0] == 0x89 && f[1] == 'P' && f[2] == 'N' && f[3] == 'G') return decode_png(f);
+  throw Error(RAYCA_ERR_UNSUPPORTED, "image: neither PNG nor JPEG (the two formats this loader decodes)");
 }
 
 inline size_t component_size(uint32_t ct) {
@@ -499,8 +507,10 @@ inline Model load_gltf_path(const std::string& path) {
       if (!im.has("uri")) throw Error(RAYCA_ERR_UNSUPPORTED, "glTF: buffer-view images are todo!() in the reference (gltf.rs:313)");
       const std::string& uri = im.at("uri").str;
       static const std::string kPng = "data:image/png;base64,";
-      if (uri.compare(0, kPng.size(), kPng) == 0) model.images.push(decode_png(base64_decode(uri.data() + kPng.size(), uri.size() - kPng.size())));
-      else model.images.push(decode_png(read_file(dir + "/" + uri)));
+      // (the reference only recognises the PNG data URI, gltf.rs:315-321; anything else is a path; the format of the bytes is
+      // guessed from their signature, image.rs:143-147)
+      if (uri.compare(0, kPng.size(), kPng) == 0) model.images.push(decode_image(base64_decode(uri.data() + kPng.size(), uri.size() - kPng.size())));
+      else model.images.push(decode_image(read_file(dir + "/" + uri)));
     }
   if (const Json* textures = doc.find("textures"))
     for (const Json& t : textures->arr) model.textures.push(Texture(Handle<Image>(t.at("source").u32())));

@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 from . import abi
-from .model import Camera, Mesh, Model, Node, PbrMaterial, Primitive, Trs, TriangleMesh
+from .model import Camera, Image, Mesh, Model, Node, PbrMaterial, Primitive, Texture, Trs, TriangleMesh
 
 _COMPONENT_DTYPE = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32,
                     5126: np.float32}
@@ -95,22 +95,43 @@ def _read_accessor(doc, buffers, index):
     return np.ascontiguousarray(rows).view(dt).reshape(count, width)
 
 
-def load_gltf(path_or_doc, base_dir=None) -> Model:
-    """Model::load_gltf_path (loader/gltf.rs:291-299)."""
+def load_gltf(path_or_doc, base_dir=None, image_decoder=None) -> Model:
+    """Model::load_gltf_path (loader/gltf.rs:291-299).  `image_decoder(file bytes) -> (H, W, 3 | 4) uint8 array` supplies
+    what this Python mirror has no library for (the C++ loader, include/rayca_gltf.hpp, decodes PNG and JPEG itself)."""
     if isinstance(path_or_doc, (str, os.PathLike)):
         base_dir = os.path.dirname(os.path.abspath(path_or_doc))
         with open(path_or_doc, "r") as fh:
             doc = json.load(fh)
     else:
         doc = path_or_doc
-    if doc.get("images"):
-        raise NotImplementedError("glTF textures need an image decoder; not available in this image")
+    if doc.get("images") and image_decoder is None:
+        raise NotImplementedError("glTF textures need an image decoder; pass image_decoder= (the C++ loader decodes PNG / JPEG itself)")
     buffers = _load_buffers(doc, base_dir or ".")
     model = Model()
+    # load_images / load_textures (gltf.rs:305-362): only the PNG data URI is recognised, anything else is a path
+    for gi in doc.get("images", []):
+        if "uri" not in gi:
+            raise NotImplementedError("buffer-view images are todo!() in the reference (gltf.rs:313)")
+        uri = gi["uri"]
+        prefix = "data:image/png;base64,"
+        if uri.startswith(prefix):
+            raw = base64.b64decode(uri[len(prefix):])
+        else:
+            with open(os.path.join(base_dir or ".", uri), "rb") as fh:
+                raw = fh.read()
+        px = np.ascontiguousarray(image_decoder(raw), np.uint8)
+        model.images.push(Image(px.shape[1], px.shape[0], abi.COLOR_RGBA8 if px.shape[2] == 4 else abi.COLOR_RGB8, px))
+    for gt in doc.get("textures", []):
+        model.textures.push(Texture(image=gt["source"]))
     # load_materials (gltf.rs:364-407); glTF defaults: color 1, metallic 1, roughness 1
     for gm in doc.get("materials", []):
         pbr = gm.get("pbrMetallicRoughness", {})
+
+        def tex(d, key):
+            return d[key]["index"] if key in d else None
         model.materials.push(PbrMaterial(color=tuple(pbr.get("baseColorFactor", [1, 1, 1, 1])),
+                                         albedo=tex(pbr, "baseColorTexture"), normal=tex(gm, "normalTexture"),
+                                         metallic_roughness=tex(pbr, "metallicRoughnessTexture"),
                                          metallic_factor=pbr.get("metallicFactor", 1.0),
                                          roughness_factor=pbr.get("roughnessFactor", 1.0)))
     # load_meshes / load_primitive / load_vertices (gltf.rs:409-492)

@@ -3,7 +3,7 @@
 //
 //   host_mirror describe <scene> <out_dir>     flatten only, dump every array of the RaycaSceneDesc (no GPU)
 //   host_mirror draw <scene> <out.rgba> [png]  SoftRenderer::draw on device 0, raw RGBA8 (+ PNG)
-//   host_mirror png <in.png> <out_dir>         decode a PNG with the loader's decoder, dump w/h/type + texels
+//   host_mirror image <in.png|jpg> <out_dir>   decode a PNG / JPEG with the loader's decoders, dump w/h/type + texels
 //   host_mirror sdtf_config <in.sdtf> <out_dir>  load an SDTF file, dump its SdtfConfig and the Config after Config::apply
 // scene "gltf:<path>" = rayca-soft/tests/gltf.rs:191-204 `gltf::cube`: the file + create_default_model()
 // scene "sdtf:<path>" = rayca-soft/tests/sdtf.rs:7-25 `run_test`: Scene::push_sdtf_from_path, nothing else
@@ -143,8 +143,8 @@ int main(int argc, char** argv) {
   }
   const std::string mode = argv[1], name = argv[2], out = argv[3];
   try {
-    if (mode == "png") {
-      const Image im = gltf_detail::decode_png(gltf_detail::read_file(name));
+    if (mode == "png" || mode == "image") {   // PNG or JPEG, by signature (rayca_gltf.hpp decode_image)
+      const Image im = gltf_detail::decode_image(gltf_detail::read_file(name));
       const std::vector<uint32_t> head = {im.w, im.h, (uint32_t)im.color_type};
       dump(out, "png_head", head);
       dump(out, "png_texels", im.data);
