@@ -49,7 +49,8 @@ enum {
   RAYCA_ERR_UNSUPPORTED = -6, /* todo!()/unimplemented!() arms of the reference, or a Config the
                                  kernels do not cover yet: fails loudly, never falls back to CPU */
   RAYCA_ERR_NO_DEVICE = -7,
-  RAYCA_ERR_BVH_DEPTH = -8
+  RAYCA_ERR_BVH_DEPTH = -8,
+  RAYCA_ERR_RCCL = -9 /* the frame-end gather of rayca_hip_render_multi: RCCL missing, or one of its calls failed */
 };
 
 /* ---- enums crossing the ABI as uint32, in the reference's #[repr(u32)] order ---------------- */
@@ -405,6 +406,41 @@ int32_t rayca_hip_render(RaycaScene* scene, const RaycaConfig* cfg, uint32_t wid
 int32_t rayca_hip_render_device(RaycaScene* scene, const RaycaConfig* cfg, uint32_t width,
                                 uint32_t height, const RaycaRenderOptions* opts,
                                 void* d_rgba8_out, void* d_rgba32f_out, RaycaStats* stats_out);
+
+/* ---- several devices, one process ----------------------------------------------------------------------
+ * Image rows shard across the devices exactly as RaycaTile shards them across ranks (bands of band_rows rows dealt
+ * round-robin); every device holds the whole scene; the only exchange is ONE gather of RGBA8 rows to scenes[0]'s device
+ * at frame end, then one de-interleave kernel there.  The multi-PROCESS form of the same frame (one rank per GPU,
+ * torch.distributed / RCCL) is rayca_amd/distributed.py on top of rayca_hip_render_device; this entry is for a host that is
+ * one process -- a Rust or C program calling this header. */
+enum {
+  /* ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd over xGMI; librccl is opened at first use (RAYCA_ERR_RCCL if it is
+   * not installed) */
+  RAYCA_GATHER_RCCL = 0,
+  /* hipMemcpyPeerAsync from every device to scenes[0]'s: no collective library involved */
+  RAYCA_GATHER_PEER_COPY = 1
+};
+typedef struct RaycaMultiOptions {
+  uint32_t traversal;        /* RAYCA_TRAVERSAL_* */
+  uint32_t collect_stats;    /* as RaycaRenderOptions.collect_stats */
+  uint32_t band_rows;        /* 0 => 8 */
+  uint32_t gather;           /* RAYCA_GATHER_* */
+  uint32_t engine;           /* RAYCA_ENGINE_* */
+  uint32_t output_on_device; /* 1: rgba8_out is device memory of scenes[0]'s device, 0: host memory */
+  uint32_t reserved[2];
+} RaycaMultiOptions;
+
+/* One frame on `count` devices.  scenes[i] is a handle created (from the same RaycaSceneDesc) on the device that renders
+ * part i; scenes[0]'s device assembles the frame.  rgba8_out receives width x height RGBA8 (host memory unless
+ * opts->output_on_device).  stats_out: NULL or `count` entries, one per device.  count == 1 is rayca_hip_render.
+ * Synchronous.  Uses frame context 0 of every scene. */
+int32_t rayca_hip_render_multi(RaycaScene* const* scenes, uint32_t count, const RaycaConfig* cfg, uint32_t width,
+                               uint32_t height, const RaycaMultiOptions* opts, void* rgba8_out,
+                               RaycaStats* stats_out);
+
+/* RAYCA_OK if librccl can be opened and offers what RAYCA_GATHER_RCCL uses, else RAYCA_ERR_RCCL with the reason in
+ * rayca_hip_last_error.  Needs no GPU. */
+int32_t rayca_hip_rccl_status(void);
 
 /* Number of rows a RaycaTile covers in a frame of `height` rows (host-side helper, no GPU). */
 uint32_t rayca_hip_tile_rows(const RaycaTile* tile, uint32_t height);

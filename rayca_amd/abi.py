@@ -22,6 +22,7 @@ ERR_OOM = -5
 ERR_UNSUPPORTED = -6
 ERR_NO_DEVICE = -7
 ERR_BVH_DEPTH = -8
+ERR_RCCL = -9
 
 # rayca-soft/src/integrator/mod.rs:32-41
 INTEGRATOR_SCRATCHER, INTEGRATOR_RAYTRACER, INTEGRATOR_FLAT = 0, 1, 2
@@ -37,6 +38,7 @@ BUILDER_REFERENCE, BUILDER_SAH = 0, 1
 ENGINE_AUTO, ENGINE_GENERAL, ENGINE_WAVEFRONT, ENGINE_FUSED = 0, 1, 2, 3
 TRAVERSAL_ORDERED, TRAVERSAL_EXHAUSTIVE = 0, 1
 CAMERA_AUTO, CAMERA_GENERATION, CAMERA_REFILL = 0, 1, 2
+GATHER_RCCL, GATHER_PEER_COPY = 0, 1
 
 
 class RaycaConfig(C.Structure):
@@ -196,6 +198,18 @@ class RaycaRenderOptions(C.Structure):
     ]
 
 
+class RaycaMultiOptions(C.Structure):
+    _fields_ = [
+        ("traversal", C.c_uint32),
+        ("collect_stats", C.c_uint32),
+        ("band_rows", C.c_uint32),
+        ("gather", C.c_uint32),
+        ("engine", C.c_uint32),
+        ("output_on_device", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
+    ]
+
+
 class RaycaStats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64),
@@ -347,6 +361,11 @@ def bind_product_signatures(lib):
                                          C.c_void_p, C.c_void_p, P(RaycaStats)]
     lib.rayca_hip_scene_primitive_order.restype = C.c_int32
     lib.rayca_hip_scene_primitive_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.rayca_hip_rccl_status.restype = C.c_int32
+    lib.rayca_hip_rccl_status.argtypes = []
+    lib.rayca_hip_render_multi.restype = C.c_int32
+    lib.rayca_hip_render_multi.argtypes = [P(C.c_void_p), C.c_uint32, P(RaycaConfig), C.c_uint32, C.c_uint32, P(RaycaMultiOptions),
+                                           C.c_void_p, P(RaycaStats)]
     return lib
 
 
@@ -354,5 +373,5 @@ PRODUCT_SYMBOLS = [
     "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_selftest", "rayca_hip_last_error", "rayca_hip_config_default",
     "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_info", "rayca_hip_render",
     "rayca_hip_render_device", "rayca_hip_tile_rows", "rayca_hip_trace_rays",
-    "rayca_hip_scene_primitive_order",
+    "rayca_hip_scene_primitive_order", "rayca_hip_render_multi", "rayca_hip_rccl_status",
 ]

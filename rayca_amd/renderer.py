@@ -132,6 +132,21 @@ class DeviceScene:
         return t, prim, uv, st.as_dict()
 
 
+def render_multi(scenes, config: Config, width: int, height: int, *, band_rows=8, gather=abi.GATHER_RCCL, traversal=abi.TRAVERSAL_ORDERED,
+                 collect_stats=False, engine=abi.ENGINE_AUTO, want_stats=False):
+    """rayca_hip_render_multi: one frame on len(scenes) devices of this process, scenes[i] = the DeviceScene that renders
+    part i (created on its own device); returns (rgba8 (H, W, 4), [stats per device] | None)."""
+    l = scenes[0]._lib
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    o = abi.RaycaMultiOptions()
+    o.traversal, o.collect_stats, o.band_rows, o.gather, o.engine = traversal, int(collect_stats), band_rows, gather, engine
+    u8 = np.zeros((height, width, 4), np.uint8)
+    st = (abi.RaycaStats * len(scenes))() if (want_stats or collect_stats) else None
+    cfg = config.to_abi()
+    lib.check(l.rayca_hip_render_multi(handles, len(scenes), C.byref(cfg), width, height, C.byref(o), u8.ctypes.data, st))
+    return u8, ([x.as_dict() for x in st] if st is not None else None)
+
+
 class SoftRenderer:
     """Drop-in for rayca_soft::SoftRenderer (scene.rs:11-14): `draw(scene, image)` renders `scene`
     with camera_draw_infos[0] into `image` (RGBA8).  Like the reference it rebuilds the BVH on
