@@ -334,7 +334,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": wl["label"], "width": W, "height": H, "triangles": info["triangle_count"],
-                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
+                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "hip_runtime_init_ms": round(info["runtime_init_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
                    "node_format": {"generation0": ("4-wide" if node_format & 1 else "binary") + (" fp16" if node_format & 4 else " f32"),
                                    "bounces": ("4-wide" if node_format & 2 else "binary") + (" fp16" if node_format & 8 else " f32"),
                                    "camera_rays": "lane-refill kernel (refill.hip)" if node_format & 1024 else "generation kernel",

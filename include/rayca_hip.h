@@ -362,8 +362,9 @@ typedef struct RaycaSceneInfo {
   uint32_t max_depth;       /* traversal stack entries per ray (LDS) the device BVH needs */
   uint32_t light_count;
   uint64_t device_bytes;    /* HBM resident for this scene */
-  float build_ms;           /* host BVH build + upload */
-  uint32_t reserved;
+  float build_ms;           /* rayca_hip_scene_create of this scene: flatten + BVH build + device layout + upload */
+  float runtime_init_ms;    /* what that call spent before it: HIP context + code object load, ~0 except for a
+                               process's first scene on a device */
 } RaycaSceneInfo;
 
 typedef struct RaycaScene RaycaScene; /* opaque: owns the device-resident scene + BVH */
@@ -373,8 +374,9 @@ typedef struct RaycaScene RaycaScene; /* opaque: owns the device-resident scene 
 uint32_t rayca_hip_version(void);
 /* number of visible HIP devices; 0 (not an error) when there is none */
 int32_t rayca_hip_device_count(void);
-/* Host-side self-checks that need no GPU (currently: the outward fp16 rounding of the steering boxes, exhaustive
- * over all finite halves).  RAYCA_OK or an error with a message in rayca_hip_last_error. */
+/* Host-side self-checks that need no GPU: the outward fp16 rounding of the steering boxes (exhaustive over all finite
+ * halves), and the multi-threaded device-layout passes of scene_create against their sequential forms on a random
+ * tree (identical arrays).  RAYCA_OK or an error with a message in rayca_hip_last_error. */
 int32_t rayca_hip_selftest(void);
 /* copies the calling thread's last error message (NUL terminated) */
 void rayca_hip_last_error(char* buf, size_t len);

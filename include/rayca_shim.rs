@@ -283,7 +283,7 @@ pub struct RaycaSceneInfo {
     pub light_count: u32,
     pub device_bytes: u64,
     pub build_ms: f32,
-    pub reserved: u32,
+    pub runtime_init_ms: f32,
 }
 
 /// opaque: owns the device-resident scene + BVH

@@ -242,11 +242,11 @@ class RaycaSceneInfo(C.Structure):
         ("light_count", C.c_uint32),
         ("device_bytes", C.c_uint64),
         ("build_ms", C.c_float),
-        ("reserved", C.c_uint32),
+        ("runtime_init_ms", C.c_float),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 def _fptr(a):

@@ -18,6 +18,8 @@
 // Checked bit for bit against the host builder (tree, boxes, order) in tests/test_gpu_parity.py.
 #include <hip/hip_runtime.h>
 
+#include <thread>
+
 #include <cfloat>
 #include <chrono>
 #include <cstdint>
@@ -540,67 +542,68 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_sm
 // BlasBuildFn: see host_scene.hpp
 bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err) {
   const uint32_t n = in.count;
-  std::vector<void*> allocs;
+  // One device allocation, carved up here, and a stream of its own: a RAYCA_BUILDER_SAH scene builds two trees at the same
+  // time from two host threads (host_scene.cpp), and each build is a chain of small launches with a counter read-back per
+  // level -- on the null stream the two chains would queue behind each other, and two dozen hipMalloc / hipFree pairs cost
+  // more than some of the levels.
+  void* pool = nullptr;
+  hipStream_t stream = nullptr;
   auto cleanup = [&] {
-    for (void* p : allocs) (void)hipFree(p);
-    allocs.clear();
-  };
-  auto dalloc = [&](size_t bytes, void** out) -> hipError_t {
-    hipError_t e = hipMalloc(out, bytes ? bytes : 4);
-    if (e == hipSuccess) allocs.push_back(*out);
-    return e;
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+      stream = nullptr;
+    }
+    if (pool) (void)hipFree(pool);
+    pool = nullptr;
   };
   static const bool verbose = getenv("RAYCA_BUILD_TIMING") != nullptr;
   auto tp = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!verbose) return;
-    (void)hipDeviceSynchronize();
+    if (stream) (void)hipStreamSynchronize(stream);
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[rayca build]     gpu %-22s %7.2f ms\n", what, std::chrono::duration<float, std::milli>(now - tp).count());
     tp = now;
   };
   HB_TRY(hipSetDevice((int)in.device));
+  HB_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  const uint32_t max_slots = n / kBig + 2, max_chunks = n / kChunk + max_slots + 2;
+  size_t pool_bytes = 0;
+  auto reserve = [&](size_t bytes) {  // offsets first, pointers once the pool exists; 256-B aligned pieces
+    const size_t at = pool_bytes;
+    pool_bytes += (std::max<size_t>(bytes, 4) + 255) / 256 * 256;
+    return at;
+  };
+  size_t off_f[9], off_u[9];
+  for (int i = 0; i < 9; ++i) off_f[i] = reserve(sizeof(float) * n);
+  for (int i = 0; i < 9; ++i) off_u[i] = reserve(sizeof(uint32_t) * ((size_t)n + 2));
+  const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
+  const size_t off_chunks[2] = {reserve((size_t)max_chunks * sizeof(uint2)), reserve((size_t)max_chunks * sizeof(uint2))};
+  HB_TRY(hipMalloc(&pool, pool_bytes));
+  char* base = static_cast<char*>(pool);
   BuildState st{};
   float* f[9];
-  for (int i = 0; i < 9; ++i) {
-    void* p = nullptr;
-    HB_TRY(dalloc(sizeof(float) * n, &p));
-    f[i] = static_cast<float*>(p);
-  }
+  for (int i = 0; i < 9; ++i) f[i] = reinterpret_cast<float*>(base + off_f[i]);
   const float* src[9] = {in.cent[0], in.cent[1], in.cent[2], in.bmin[0], in.bmin[1], in.bmin[2], in.bmax[0], in.bmax[1], in.bmax[2]};
-  for (int i = 0; i < 9; ++i) HB_TRY(hipMemcpy(f[i], src[i], sizeof(float) * n, hipMemcpyHostToDevice));
+  for (int i = 0; i < 9; ++i) HB_TRY(hipMemcpyAsync(f[i], src[i], sizeof(float) * n, hipMemcpyHostToDevice, stream));
   for (int c = 0; c < 3; ++c) {
     st.cent[c] = f[c];
     st.bmin[c] = f[3 + c];
     st.bmax[c] = f[6 + c];
   }
   uint32_t* u[9];
-  for (int i = 0; i < 9; ++i) {
-    void* p = nullptr;
-    HB_TRY(dalloc(sizeof(uint32_t) * ((size_t)n + 2), &p));
-    u[i] = static_cast<uint32_t*>(p);
-  }
+  for (int i = 0; i < 9; ++i) u[i] = reinterpret_cast<uint32_t*>(base + off_u[i]);
   st.order = u[0]; st.tmp = u[1]; st.rank = u[2]; st.hole_pos = u[3]; st.filler_pos = u[4];
   uint32_t* lists[2] = {u[5], u[6]};
   st.small_nodes = u[7];
   st.small_levels = u[8];
-  void* pn = nullptr;
-  HB_TRY(dalloc(sizeof(DNode) * (2 * (size_t)n + 2), &pn));
-  st.nodes = static_cast<DNode*>(pn);
-  void* pc = nullptr;
-  HB_TRY(dalloc(64, &pc));
-  st.node_count = static_cast<uint32_t*>(pc);
+  st.nodes = reinterpret_cast<DNode*>(base + off_nodes);
+  st.node_count = reinterpret_cast<uint32_t*>(base + off_counts);
   st.chunk_count = st.node_count + 3;
   st.slot_count = st.node_count + 4;
-  const uint32_t max_slots = n / kBig + 2, max_chunks = n / kChunk + max_slots + 2;
-  void* pg = nullptr;
-  HB_TRY(dalloc((size_t)max_slots * kBinWords * 4, &pg));
-  st.gbins = static_cast<uint32_t*>(pg);
-  for (int i = 0; i < 2; ++i) {
-    void* pch = nullptr;
-    HB_TRY(dalloc((size_t)max_chunks * sizeof(uint2), &pch));
-    st.chunks[i] = static_cast<uint2*>(pch);
-  }
+  st.gbins = reinterpret_cast<uint32_t*>(base + off_gbins);
+  for (int i = 0; i < 2; ++i) st.chunks[i] = reinterpret_cast<uint2*>(base + off_chunks[i]);
   uint32_t* next_count = st.node_count + 1;
   st.small_count = st.node_count + 2;
   st.seed_origin = in.seed_origin ? 1u : 0u;
@@ -608,7 +611,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
 
   std::vector<uint32_t> ident(n);
   for (uint32_t i = 0; i < n; ++i) ident[i] = i;
-  HB_TRY(hipMemcpy(st.order, ident.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  HB_TRY(hipMemcpyAsync(st.order, ident.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream));
   DNode root{};
   for (int c = 0; c < 3; ++c) {
     root.a[c] = in.root_min[c];
@@ -616,11 +619,12 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   }
   root.offset = 0; root.count = n; root.left = root.right = -1;
   root.big = n > kBig ? 0u : RAYCA_NONE;
-  HB_TRY(hipMemcpy(st.nodes, &root, sizeof root, hipMemcpyHostToDevice));
+  HB_TRY(hipMemcpyAsync(st.nodes, &root, sizeof root, hipMemcpyHostToDevice, stream));
   const uint32_t init[5] = {1u, 0u, 0u, 0u, 0u};
-  HB_TRY(hipMemcpy(st.node_count, init, sizeof init, hipMemcpyHostToDevice));
+  HB_TRY(hipMemcpyAsync(st.node_count, init, sizeof init, hipMemcpyHostToDevice, stream));
   const uint32_t zero = 0;
-  HB_TRY(hipMemcpy(lists[0], &zero, 4, hipMemcpyHostToDevice));  // level 0: the root
+  HB_TRY(hipMemcpyAsync(lists[0], &zero, 4, hipMemcpyHostToDevice, stream));  // level 0: the root
+  HB_TRY(hipStreamSynchronize(stream));  // (the sources above are locals and caller memory: staged before they go away)
 
   lap("alloc + upload");
   uint32_t n_active = n > 0 ? 1u : 0u;
@@ -630,7 +634,8 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     n_chunks = (n + kChunk - 1) / kChunk;
     std::vector<uint2> rc(n_chunks);
     for (uint32_t k = 0; k < n_chunks; ++k) rc[k] = make_uint2(0u, k);
-    HB_TRY(hipMemcpy(st.chunks[0], rc.data(), sizeof(uint2) * n_chunks, hipMemcpyHostToDevice));
+    HB_TRY(hipMemcpyAsync(st.chunks[0], rc.data(), sizeof(uint2) * n_chunks, hipMemcpyHostToDevice, stream));
+    HB_TRY(hipStreamSynchronize(stream));
   }
   uint32_t levels_run = 0, blocks_run = 0;
   for (uint32_t level = 0; level < in.max_depth && n_active > 0; ++level) {
@@ -639,17 +644,18 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     const auto lt0 = std::chrono::steady_clock::now();
     const uint32_t blocks_this_level = n_active;
     if (n_chunks) {  // big nodes of this level: bins by many workgroups
-      hipLaunchKernelGGL(k_bin_init, dim3((n_slots * 3 * 64 + kB - 1) / kB), dim3(kB), 0, 0, st, n_slots);
-      hipLaunchKernelGGL(k_bin_big, dim3(n_chunks), dim3(kB), 0, 0, st, st.chunks[level & 1]);
+      hipLaunchKernelGGL(k_bin_init, dim3((n_slots * 3 * 64 + kB - 1) / kB), dim3(kB), 0, stream, st, n_slots);
+      hipLaunchKernelGGL(k_bin_big, dim3(n_chunks), dim3(kB), 0, stream, st, st.chunks[level & 1]);
       HB_TRY(hipGetLastError());
     }
-    HB_TRY(hipMemset(next_count, 0, 4));
-    HB_TRY(hipMemset(st.chunk_count, 0, 8));  // chunk_count, slot_count
-    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(kB), 0, 0, st, lists[level & 1], lists[(level + 1) & 1], next_count,
+    HB_TRY(hipMemsetAsync(next_count, 0, 4, stream));
+    HB_TRY(hipMemsetAsync(st.chunk_count, 0, 8, stream));  // chunk_count, slot_count
+    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(kB), 0, stream, st, lists[level & 1], lists[(level + 1) & 1], next_count,
                        st.chunks[(level + 1) & 1], level);
     HB_TRY(hipGetLastError());
     uint32_t counters[5];
-    HB_TRY(hipMemcpy(counters, st.node_count, sizeof counters, hipMemcpyDeviceToHost));
+    HB_TRY(hipMemcpyAsync(counters, st.node_count, sizeof counters, hipMemcpyDeviceToHost, stream));
+    HB_TRY(hipStreamSynchronize(stream));
     n_active = counters[1];
     n_chunks = counters[3];
     n_slots = counters[4];
@@ -664,29 +670,42 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   }
   lap("levels");
   uint32_t n_small = 0;
-  HB_TRY(hipMemcpy(&n_small, st.small_count, 4, hipMemcpyDeviceToHost));
+  HB_TRY(hipMemcpyAsync(&n_small, st.small_count, 4, hipMemcpyDeviceToHost, stream));
+  HB_TRY(hipStreamSynchronize(stream));
   if (verbose) fprintf(stderr, "[rayca build]   gpu: %u primitives, %u levels, %u node blocks, %u small subtrees\n", n, levels_run, blocks_run, n_small);
   if (n_small) {
-    hipLaunchKernelGGL(k_build_small, dim3((n_small + 63) / 64), dim3(64), 0, 0, st, n_small);
+    hipLaunchKernelGGL(k_build_small, dim3((n_small + 63) / 64), dim3(64), 0, stream, st, n_small);
     HB_TRY(hipGetLastError());
   }
   lap("small subtrees");
   uint32_t node_count = 0;
-  HB_TRY(hipMemcpy(&node_count, st.node_count, 4, hipMemcpyDeviceToHost));
-  std::vector<DNode> nodes(node_count);
-  HB_TRY(hipMemcpy(nodes.data(), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost));
+  HB_TRY(hipMemcpyAsync(&node_count, st.node_count, 4, hipMemcpyDeviceToHost, stream));
+  HB_TRY(hipStreamSynchronize(stream));
+  std::vector<DNode, DefaultInitAllocator<DNode>> nodes(node_count);
+  HB_TRY(hipMemcpyAsync(nodes.data(), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost, stream));
   order.resize(n);
-  HB_TRY(hipMemcpy(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+  HB_TRY(hipMemcpyAsync(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream));
+  HB_TRY(hipStreamSynchronize(stream));
   arena.resize(node_count);
-  for (uint32_t i = 0; i < node_count; ++i) {
-    for (int c = 0; c < 3; ++c) {
-      arena[i].a[c] = nodes[i].a[c];
-      arena[i].b[c] = nodes[i].b[c];
-    }
-    arena[i].offset = nodes[i].offset;
-    arena[i].count = nodes[i].count;
-    arena[i].left = nodes[i].left;
-    arena[i].right = nodes[i].right;
+  {
+    const unsigned nt = std::max(1u, std::min(host_threads() / 2u, node_count / 65536u + 1u));
+    auto convert = [&](uint32_t b, uint32_t e) {
+      for (uint32_t i = b; i < e; ++i) {
+        for (int c = 0; c < 3; ++c) {
+          arena[i].a[c] = nodes[i].a[c];
+          arena[i].b[c] = nodes[i].b[c];
+        }
+        arena[i].offset = nodes[i].offset;
+        arena[i].count = nodes[i].count;
+        arena[i].left = nodes[i].left;
+        arena[i].right = nodes[i].right;
+      }
+    };
+    std::vector<std::thread> pool;
+    const uint32_t per = (node_count + nt - 1) / nt;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(convert, std::min(node_count, t * per), std::min(node_count, (t + 1) * per));
+    convert(0, std::min(node_count, per));
+    for (std::thread& th : pool) th.join();
   }
   lap("download + convert");
   cleanup();

@@ -22,13 +22,28 @@
 #include <cmath>
 #include <thread>
 
+#include <sched.h>
+
 namespace rayca {
+
+unsigned host_threads() {
+  static const unsigned n = [] {
+    if (const char* e = getenv("RAYCA_HOST_THREADS")) return std::max(1u, (unsigned)atoi(e));
+    unsigned avail = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) avail = (unsigned)CPU_COUNT(&set);
+    return std::max(1u, std::min(avail, 16u));
+  }();
+  return n;
+}
+
 namespace {
 
 // fn(begin, end) over [0, n) on all host threads
 template <class Fn>
 void parallel_chunks(size_t n, Fn fn) {
-  const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 4096 + 1));
+  const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n / 4096 + 1));
   if (nt <= 1) {
     fn(0, n);
     return;
@@ -40,9 +55,6 @@ void parallel_chunks(size_t n, Fn fn) {
   for (std::thread& th : pool) th.join();
 }
 
-struct Box {
-  F4 a, b;
-};
 inline Box empty_box() { return Box{point3(FLT_MAX, FLT_MAX, FLT_MAX), point3(-FLT_MAX, -FLT_MAX, -FLT_MAX)}; }
 inline Box origin_box() { return Box{point3(0, 0, 0), point3(0, 0, 0)}; }  // AABB::default()  aabb.rs:9-13
 inline void grow(Box& bx, F4 p) {
@@ -108,12 +120,6 @@ thread_local BlasBuildFn g_device_builder = nullptr;  // per thread: scenes may 
 thread_local uint32_t g_device_ordinal = 0;
 // below this many primitives the host builder is faster than a level-by-level sequence of launches
 constexpr uint32_t kDeviceBuildMin = 4096;
-
-struct BuildNode {
-  Box bounds;
-  uint32_t offset = 0, count = 0;  // primitive range (leaf) -- count == 0 => inner
-  int32_t left = -1, right = -1;   // indices into the arena
-};
 
 struct BlasBuilder {
   const HostScene* scene;
@@ -280,32 +286,6 @@ struct BlasBuilder {
   }
 };
 
-// arena tree -> the reference's node numbering: a node's two children are appended when the node
-// is split, and splits happen in DFS pre-order (blas.rs:302-311).
-void to_reference_layout(const std::vector<BuildNode>& arena, std::vector<RefNode>& out) {
-  out.clear();
-  out.reserve(arena.size() + 2);
-  out.push_back(RefNode{arena[0].bounds.a, arena[0].bounds.b, arena[0].offset, arena[0].count});
-  out.push_back(RefNode{point3(0, 0, 0), point3(0, 0, 0), 0, 0});  // slot 1 unused (blas.rs:254-256)
-  struct Item { int32_t arena_idx; uint32_t ref_idx; };
-  std::vector<Item> stack{{0, 0}};
-  stack.reserve(512);
-  while (!stack.empty()) {
-    const Item it = stack.back();
-    stack.pop_back();
-    const BuildNode& n = arena[it.arena_idx];
-    if (n.left < 0) continue;
-    const uint32_t li = (uint32_t)out.size();
-    const BuildNode &l = arena[n.left], &r = arena[n.right];
-    out.push_back(RefNode{l.bounds.a, l.bounds.b, l.offset, l.count});
-    out.push_back(RefNode{r.bounds.a, r.bounds.b, r.offset, r.count});
-    out[it.ref_idx].offset = li;
-    out[it.ref_idx].count = 0;
-    stack.push_back({n.right, li + 1});  // right is split after the whole left subtree
-    stack.push_back({n.left, li});
-  }
-}
-
 // ---- TLAS build  bvh/tlas.rs:74-134 --------------------------------------------------------------
 struct TNode {
   Box bounds;
@@ -461,18 +441,93 @@ struct DevBuilder {
     need = 1;
     return head;
   }
-  uint32_t emit_blas_node(const HostBlas& bl, uint32_t base, uint32_t ref_idx, uint32_t& need) {
-    const RefNode& rn = bl.nodes[ref_idx];
-    const Box box{rn.a, rn.b};
-    if (rn.count != 0 || (ref_idx == 0 && bl.prims.empty())) return emit_leaf(base + rn.offset, rn.count, box, need);
+  // The BLAS below its root, without recursion.  Children sit behind their parents in the arena (both builders append
+  // them that way; checked), so one backward pass gives every subtree's device-node count and stack need, one forward
+  // pass gives every node its index -- the pre-order numbering the recursive form below produces: a node, its left
+  // subtree, its right subtree -- and then every node is written independently, by all host threads.  (The recursive
+  // walk over an arena in level order was 36 ms of cache misses for the atrium's 543 k nodes.)
+  bool allow_flat = true;  // (the self-test switches it off to compare against the recursive form)
+  bool emit_blas_flat(const HostBlas& bl, uint32_t base, uint32_t& root_ref, uint32_t& need) {
+    const std::vector<BuildNode>& a = bl.nodes;
+    const size_t n = a.size();
+    if (n < 4096 || !allow_flat) return false;  // small trees: the recursive form
+    std::vector<uint32_t> size(n), stack_need(n);
+    for (size_t i = n; i-- > 0;) {
+      const BuildNode& bn = a[i];
+      if (bn.left < 0) {  // leaf: a packed reference, or a chain of ceil(count / 64) - 1 nodes
+        const uint32_t chain = bn.count > kLeafMaxPrims ? (bn.count + kLeafMaxPrims - 1) / kLeafMaxPrims - 1 : 0u;
+        size[i] = chain;
+        stack_need[i] = chain ? 1u : 0u;
+      } else {
+        if ((size_t)bn.left <= i || (size_t)bn.right <= i || (size_t)bn.left >= n || (size_t)bn.right >= n) return false;
+        size[i] = 1u + size[bn.left] + size[bn.right];
+        stack_need[i] = 1u + std::max(stack_need[bn.left], stack_need[bn.right]);
+      }
+    }
+    const uint32_t first = (uint32_t)s.dev_nodes.size();
+    std::vector<uint32_t> index(n);  // device index of an inner node / of the head of a leaf's chain
+    index[0] = first;
+    for (size_t i = 0; i < n; ++i) {
+      const BuildNode& bn = a[i];
+      if (bn.left < 0) continue;
+      index[bn.left] = index[i] + 1u;
+      index[bn.right] = index[i] + 1u + size[bn.left];
+    }
+    s.dev_nodes.resize((size_t)first + size[0]);
+    auto ref_of = [&](size_t i) -> uint32_t {  // what the parent stores for child i
+      const BuildNode& bn = a[i];
+      if (bn.left >= 0) return index[i];
+      if (bn.count == 0) return kNoChild;
+      return bn.count <= kLeafMaxPrims ? leaf_ref(base + bn.offset, bn.count) : index[i];
+    };
+    parallel_chunks(n, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const BuildNode& bn = a[i];
+        if (bn.left >= 0) {
+          DevNode& d = s.dev_nodes[index[i]];
+          std::memset(&d, 0, sizeof d);
+          put_box(d, 0, a[bn.left].bounds);
+          put_box(d, 1, a[bn.right].bounds);
+          d.left = ref_of((size_t)bn.left);
+          d.right = ref_of((size_t)bn.right);
+        } else if (bn.count > kLeafMaxPrims) {  // the chain of emit_leaf
+          uint32_t cur = index[i], f = base + bn.offset, count = bn.count;
+          for (;;) {
+            DevNode& d = s.dev_nodes[cur];
+            std::memset(&d, 0, sizeof d);
+            put_box(d, 0, bn.bounds);
+            put_box(d, 1, bn.bounds);
+            d.left = leaf_ref(f, kLeafMaxPrims);
+            f += kLeafMaxPrims;
+            count -= kLeafMaxPrims;
+            if (count <= kLeafMaxPrims) {
+              d.right = leaf_ref(f, count);
+              break;
+            }
+            d.right = cur + 1u;
+            ++cur;
+          }
+        }
+      }
+    });
+    root_ref = ref_of(0);
+    need = stack_need[0];
+    return true;
+  }
+  uint32_t emit_blas_node(const HostBlas& bl, uint32_t base, uint32_t idx, uint32_t& need) {
+    if (idx == 0) {
+      uint32_t ref = 0;
+      if (emit_blas_flat(bl, base, ref, need)) return ref;
+    }
+    const BuildNode& bn = bl.nodes[idx];
+    if (bn.left < 0) return emit_leaf(base + bn.offset, bn.count, bn.bounds, need);
     const uint32_t n = new_node();
-    const RefNode &l = bl.nodes[rn.offset], &r = bl.nodes[rn.offset + 1];
-    put_box(s.dev_nodes[n], 0, Box{l.a, l.b});
-    put_box(s.dev_nodes[n], 1, Box{r.a, r.b});
+    put_box(s.dev_nodes[n], 0, bl.nodes[bn.left].bounds);
+    put_box(s.dev_nodes[n], 1, bl.nodes[bn.right].bounds);
     uint32_t nl = 0, nr = 0;
-    const uint32_t lr = emit_blas_node(bl, base, rn.offset, nl);
+    const uint32_t lr = emit_blas_node(bl, base, (uint32_t)bn.left, nl);
     s.dev_nodes[n].left = lr;
-    const uint32_t rr = emit_blas_node(bl, base, rn.offset + 1, nr);
+    const uint32_t rr = emit_blas_node(bl, base, (uint32_t)bn.right, nr);
     s.dev_nodes[n].right = rr;
     need = 1 + std::max(nl, nr);
     return n;
@@ -481,8 +536,7 @@ struct DevBuilder {
   uint32_t emit_blas_chain(uint32_t offset, uint32_t count, const Box& leaf_box, uint32_t& need) {
     if (count == 1) return emit_blas_node(s.blas[offset], blas_base[offset], 0, need);
     const uint32_t n = new_node();
-    const RefNode& root = s.blas[offset].nodes[0];
-    put_box(s.dev_nodes[n], 0, Box{root.a, root.b});
+    put_box(s.dev_nodes[n], 0, s.blas[offset].nodes[0].bounds);
     put_box(s.dev_nodes[n], 1, leaf_box);
     uint32_t nl = 0, nr = 0;
     const uint32_t lr = emit_blas_node(s.blas[offset], blas_base[offset], 0, nl);
@@ -532,14 +586,8 @@ struct WideBuilder {
       out[1].b[i] = n.q[6 + i];
     }
   }
-  uint32_t build(uint32_t bin_ref, uint32_t& need) {
-    if ((bin_ref & kLeafFlag) || bin_ref == kNoChild) {
-      need = 0;
-      return bin_ref;
-    }
-    // iterative over an explicit work list would be needed for pathological depth only; the binary
-    // chains for big leaves are collapsed 3 links at a time here
-    Kid kids[4];
+  // the up-to-four children a wide node gets for binary node `bin_ref`
+  int expand(uint32_t bin_ref, Kid kids[4]) const {
     int k = 2;
     kids_of(bin_ref, kids);
     while (k < 4) {
@@ -562,17 +610,86 @@ struct WideBuilder {
       kids[best + 1] = two[1];
       ++k;
     }
-    const uint32_t idx = (uint32_t)s.dev_nodes4.size();
-    s.dev_nodes4.emplace_back();
+    return k;
+  }
+
+  // Subtrees a few levels down are collapsed by all host threads into arrays of their own (numbered from 0, pre-order)
+  // and spliced in when the top of the tree -- built by this thread, in the same pre-order -- reaches them: the result is
+  // the array the purely sequential recursion produces, node for node.
+  struct Task {
+    uint32_t bin_root = 0, need = 0;
+    std::vector<DevNode4> nodes;
+  };
+  std::vector<Task> tasks;
+  std::vector<std::pair<uint32_t, uint32_t>> task_of;  // (binary ref, task), sorted by ref
+  bool allow_parallel = true;  // (the self-test switches it off to compare against the sequential recursion)
+
+  void collect(uint32_t bin_ref, int depth) {
+    if ((bin_ref & kLeafFlag) || bin_ref == kNoChild) return;
+    if (depth == 0) {
+      tasks.emplace_back();
+      tasks.back().bin_root = bin_ref;
+      return;
+    }
+    Kid kids[4];
+    const int k = expand(bin_ref, kids);
+    for (int i = 0; i < k; ++i) collect(kids[i].ref, depth - 1);
+  }
+
+  uint32_t build(uint32_t bin_ref, uint32_t& need) {
+    tasks.clear();
+    task_of.clear();
+    if (allow_parallel && s.dev_nodes.size() >= 65536 && host_threads() > 1) {
+      collect(bin_ref, 3);
+      std::atomic<size_t> next{0};
+      auto worker = [&] {
+        for (size_t t; (t = next.fetch_add(1)) < tasks.size();) build_into(tasks[t].nodes, tasks[t].bin_root, tasks[t].need, false);
+      };
+      std::vector<std::thread> pool;
+      const unsigned nt = (unsigned)std::min<size_t>(host_threads(), tasks.size());
+      for (unsigned i = 1; i < nt; ++i) pool.emplace_back(worker);
+      worker();
+      for (std::thread& th : pool) th.join();
+      for (size_t t = 0; t < tasks.size(); ++t) task_of.push_back({tasks[t].bin_root, (uint32_t)t});
+      std::sort(task_of.begin(), task_of.end());
+    }
+    return build_into(s.dev_nodes4, bin_ref, need, true);
+  }
+
+  uint32_t build_into(std::vector<DevNode4>& out, uint32_t bin_ref, uint32_t& need, bool top) {
+    if ((bin_ref & kLeafFlag) || bin_ref == kNoChild) {
+      need = 0;
+      return bin_ref;
+    }
+    if (top && !task_of.empty()) {
+      const auto it = std::lower_bound(task_of.begin(), task_of.end(), std::make_pair(bin_ref, 0u));
+      if (it != task_of.end() && it->first == bin_ref) {  // splice the finished subtree: local indices + base
+        Task& t = tasks[it->second];
+        const uint32_t base = (uint32_t)out.size();
+        out.insert(out.end(), t.nodes.begin(), t.nodes.end());
+        for (size_t i = base; i < out.size(); ++i)
+          for (int c = 0; c < 4; ++c)
+            if (!(out[i].child[c] & kLeafFlag) && out[i].child[c] != kNoChild) out[i].child[c] += base;
+        std::vector<DevNode4>().swap(t.nodes);
+        need = t.need;
+        return base;  // a task's root is its node 0
+      }
+    }
+    // iterative over an explicit work list would be needed for pathological depth only; the binary
+    // chains for big leaves are collapsed 3 links at a time here
+    Kid kids[4];
+    const int k = expand(bin_ref, kids);
+    const uint32_t idx = (uint32_t)out.size();
+    out.emplace_back();
     uint32_t child_refs[4], child_need[4] = {0, 0, 0, 0};
     uint32_t worst = 0;
     for (int i = 0; i < k; ++i) {
       uint32_t nd = 0;
-      child_refs[i] = build(kids[i].ref, nd);
+      child_refs[i] = build_into(out, kids[i].ref, nd, top);
       child_need[i] = nd;
       worst = std::max(worst, nd);
     }
-    DevNode4& w = s.dev_nodes4[idx];
+    DevNode4& w = out[idx];
     for (int i = 0; i < 4; ++i) {
       if (i < k) {
         for (int a = 0; a < 3; ++a) {
@@ -641,6 +758,70 @@ void set_ext(PrimExt& e, int k, Color c, F4 n, F4 t, F4 b, F2 uv) {
 
 }  // namespace
 
+// Self-check of the two parallel layout passes against their recursive forms on a random tree (uneven depths, mostly small leaves
+// and some of 65..264 primitives so that the 64-primitive chains occur): the arrays must be identical, byte for byte.
+int32_t selftest_device_layouts(std::string& err) {
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto next = [&rng]() {
+    rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+    return rng;
+  };
+  auto rnd = [&](float lo, float hi) { return lo + (hi - lo) * (float)((next() >> 40) & 0xFFFFFF) / 16777216.0f; };
+  HostBlas bl;
+  const uint32_t prims = 1u << 20;
+  bl.prims.resize(prims);
+  for (uint32_t i = 0; i < prims; ++i) bl.prims[i] = i;
+  bl.nodes.emplace_back();
+  bl.nodes[0].offset = 0;
+  bl.nodes[0].count = prims;
+  bl.nodes[0].bounds = Box{point3(-1, -1, -1), point3(1, 1, 1)};
+  for (size_t i = 0; i < bl.nodes.size(); ++i) {  // breadth-first: children behind their parent, like the builders
+    const BuildNode n = bl.nodes[i];
+    const uint32_t leaf_max = (next() % 16u == 0u) ? 65u + (uint32_t)(next() % 200u) : 1u + (uint32_t)(next() % 8u);
+    if (n.count <= leaf_max) continue;
+    const uint32_t cut = 1u + (uint32_t)(next() % (n.count - 1u));
+    BuildNode l, r;
+    l.offset = n.offset; l.count = cut;
+    r.offset = n.offset + cut; r.count = n.count - cut;
+    for (BuildNode* c : {&l, &r}) {
+      const float x0 = rnd(-1, 1), y0 = rnd(-1, 1), z0 = rnd(-1, 1);
+      c->bounds = Box{point3(x0, y0, z0), point3(x0 + rnd(0, 0.5f), y0 + rnd(0, 0.5f), z0 + rnd(0, 0.5f))};
+    }
+    bl.nodes[i].left = (int32_t)bl.nodes.size();
+    bl.nodes.push_back(l);
+    bl.nodes[i].right = (int32_t)bl.nodes.size();
+    bl.nodes.push_back(r);
+    bl.nodes[i].count = 0;
+  }
+  HostScene a, b;
+  uint32_t ref[2], need[2], ref4[2], need4[2];
+  HostScene* scenes[2] = {&a, &b};
+  for (int pass = 0; pass < 2; ++pass) {
+    HostScene& s = *scenes[pass];
+    s.blas.push_back(bl);
+    DevBuilder db{s, {0u}};
+    db.pad_rel = 1.52587890625e-05f;
+    db.pad_abs = 1e-6f;
+    db.allow_flat = pass == 1;
+    ref[pass] = db.emit_blas_node(s.blas[0], 0, 0, need[pass]);
+    WideBuilder wb{s};
+    wb.allow_parallel = pass == 1;
+    ref4[pass] = wb.build(ref[pass], need4[pass]);
+  }
+  if (a.dev_nodes.size() < 65536) { err = "layout self-test: the random tree came out too small to exercise the parallel passes"; return RAYCA_ERR_BAD_ARG; }
+  if (ref[0] != ref[1] || need[0] != need[1] || a.dev_nodes.size() != b.dev_nodes.size() ||
+      std::memcmp(a.dev_nodes.data(), b.dev_nodes.data(), a.dev_nodes.size() * sizeof(DevNode)) != 0) {
+    err = "layout self-test: the flat binary-node pass differs from the recursive one";
+    return RAYCA_ERR_BAD_ARG;
+  }
+  if (ref4[0] != ref4[1] || need4[0] != need4[1] || a.dev_nodes4.size() != b.dev_nodes4.size() ||
+      std::memcmp(a.dev_nodes4.data(), b.dev_nodes4.data(), a.dev_nodes4.size() * sizeof(DevNode4)) != 0) {
+    err = "layout self-test: the parallel 4-wide collapse differs from the sequential one";
+    return RAYCA_ERR_BAD_ARG;
+  }
+  return RAYCA_OK;
+}
+
 // Self-check of the outward fp16 rounding the steering boxes rely on: every finite half maps to itself in both
 // directions, and for values between two neighbouring halves `down` and `up` return exactly those neighbours.
 int32_t selftest_half_rounding(std::string& err) {
@@ -681,7 +862,7 @@ void set_device_blas_builder(BlasBuildFn fn, uint32_t device) {
   g_device_ordinal = device;
 }
 
-int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err) {
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err, const std::function<void()>& on_order_ready) {
   // RAYCA_BUILD_TIMING=1: phase times of the host build on stderr
   static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
@@ -776,6 +957,15 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   };
   std::vector<TriJob> jobs;
   std::vector<HostBlas> blas(models.size());
+  {  // one allocation for the flatten-order array: growing it piecewise re-copied 0.5 KB per triangle several times over
+    size_t total = 2 * light_nodes.size();
+    for (uint32_t node : mesh_nodes) {
+      const RaycaMesh& mesh = d.meshes[d.nodes[node].mesh];
+      for (uint32_t pi = mesh.first_primitive; pi < mesh.first_primitive + mesh.primitive_count && pi < d.primitive_count; ++pi)
+        total += d.primitives[pi].geometry == RAYCA_GEOMETRY_SPHERE ? 1u : d.primitives[pi].index_count / 3u;
+    }
+    s.prims.reserve(total);
+  }
   for (size_t m = 0; m < models.size(); ++m) {
     blas[m].model = models[m];
     for (uint32_t node : mesh_nodes) {
@@ -810,8 +1000,11 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         for (uint32_t at = 0; at < ntri; at += 8192)  // pieces, so that one huge mesh still feeds every thread
           jobs.push_back(TriJob{node, pi, at, first_out + at, std::min<uint32_t>(8192u, ntri - at), tangent_matrix, normal_matrix});
         s.prims.resize((size_t)first_out + ntri);
-        blas[m].prims.reserve(blas[m].prims.size() + ntri);
-        for (uint32_t t = 0; t < ntri; ++t) blas[m].prims.push_back(first_out + t);
+        {
+          const size_t at = blas[m].prims.size();
+          blas[m].prims.resize(at + ntri);  // (geometric growth: a model of many small meshes must not reallocate per mesh)
+          for (uint32_t t = 0; t < ntri; ++t) blas[m].prims[at + t] = first_out + t;
+        }
         s.triangle_count += ntri;
       }
     }
@@ -843,6 +1036,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       }
     }
   }
+  lap("flatten: graph, slots");
   if (!jobs.empty()) {  // fill the reserved triangle slots with all host threads
     std::atomic<int> failed{0};
     const char* first_error = nullptr;
@@ -855,10 +1049,13 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         const RaycaPrimitive& p = d.primitives[job.pi];
         for (uint32_t t = 0; t < job.count; ++t) {
           const uint32_t tri = job.first_tri + t;
-          HostPrim hp{};
+          HostPrim& hp = s.prims[job.first_out + t];  // written in place, every field (the array is not pre-zeroed)
           hp.kind = RAYCA_GEOMETRY_TRIANGLE_MESH;
           hp.node = job.node;
           hp.material = p.material;
+          hp.center = point3(0, 0, 0);
+          hp.radius = 0.0f;
+          std::memset(&hp.ext, 0, sizeof hp.ext);
           const char* problem = nullptr;
           for (int k = 0; k < 3; ++k) {
             uint32_t idx;
@@ -882,11 +1079,10 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           hp.ext.kind = hp.kind;
           hp.ext.node = job.node;
           hp.src = job.first_out + t;
-          s.prims[hp.src] = hp;
         }
       }
     };
-    const unsigned nthreads = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), (unsigned)jobs.size()));
+    const unsigned nthreads = std::max(1u, std::min<unsigned>(host_threads(), (unsigned)jobs.size()));
     std::vector<std::thread> pool;
     for (unsigned i = 1; i < nthreads; ++i) pool.emplace_back(worker);
     worker();
@@ -900,23 +1096,33 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   lap("world-space vertices, boxes");
 
   // ---- Tlas::new: one BLAS per model ------------------------------------------------------------
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned hw = host_threads();
   unsigned par_levels = 0;
   while ((1u << par_levels) < hw) ++par_levels;
   std::vector<Box> blas_root(blas.size());
   // reference order of every primitive inside its BLAS (needed by both builders: it is the tie rule)
   std::vector<std::vector<uint32_t>> ref_prims(blas.size());
-  std::vector<std::vector<RefNode>> ref_nodes(blas.size());
+  std::vector<std::vector<BuildNode>> ref_nodes(blas.size());
   static const bool host_only = getenv("RAYCA_HOST_BUILD") != nullptr;
-  std::string build_err;
-  auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<RefNode>& nodes) {
+  // (thread_local: captured here because the two trees of a RAYCA_BUILDER_SAH scene are built by two threads)
+  const BlasBuildFn device_builder = g_device_builder;
+  const uint32_t device_ordinal = g_device_ordinal;
+  std::mutex lap_mu;
+  auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<BuildNode>& nodes, std::string& build_err, bool quiet) {
+    auto lap = [&](const char* what) {
+      if (!timing || quiet) return;
+      std::lock_guard<std::mutex> lock(lap_mu);
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[rayca build] %-28s %8.1f ms\n", what, std::chrono::duration<float, std::milli>(now - t_prev).count());
+      t_prev = now;
+    };
     BlasBuilder bb{&s, &order, use_bvh ? 255u : 0u, par_levels + 1, seed_origin};
     std::vector<BuildNode> arena(1);
     arena[0].offset = 0;
     arena[0].count = (uint32_t)order.size();
     arena[0].bounds = bb.range_bounds(0, arena[0].count);
     const uint32_t n = arena[0].count;
-    if (g_device_builder && !host_only && use_bvh && n >= kDeviceBuildMin) {
+    if (device_builder && !host_only && use_bvh && n >= kDeviceBuildMin) {
       // the same recursion, level by level on the GPU (bvh_build.hip): identical tree, boxes and order
       std::vector<float> soa[9];
       for (auto& v : soa) v.resize(n);
@@ -940,41 +1146,48 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       in.root_max[0] = arena[0].bounds.b.x; in.root_max[1] = arena[0].bounds.b.y; in.root_max[2] = arena[0].bounds.b.z;
       in.seed_origin = seed_origin;
       in.max_depth = 255u;
-      in.device = g_device_ordinal;
+      in.device = device_ordinal;
       std::vector<uint32_t> perm;
       std::vector<BlasBuildNode> dn;
-      if (!g_device_builder(in, perm, dn, build_err)) return false;
+      if (!device_builder(in, perm, dn, build_err)) return false;
       lap("  gpu build (total)");
       std::vector<uint32_t> permuted(n);
-      for (uint32_t i = 0; i < n; ++i) permuted[i] = order[perm[i]];
+      parallel_chunks(n, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) permuted[i] = order[perm[i]];
+      });
       order.swap(permuted);
       arena.resize(dn.size());
-      for (size_t i = 0; i < dn.size(); ++i) {
-        arena[i].bounds = Box{point3(dn[i].a[0], dn[i].a[1], dn[i].a[2]), point3(dn[i].b[0], dn[i].b[1], dn[i].b[2])};
-        arena[i].offset = dn[i].offset;
-        arena[i].count = dn[i].count;
-        arena[i].left = dn[i].left;
-        arena[i].right = dn[i].right;
-      }
+      parallel_chunks(dn.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          arena[i].bounds = Box{point3(dn[i].a[0], dn[i].a[1], dn[i].a[2]), point3(dn[i].b[0], dn[i].b[1], dn[i].b[2])};
+          arena[i].offset = dn[i].offset;
+          arena[i].count = dn[i].count;
+          arena[i].left = dn[i].left;
+          arena[i].right = dn[i].right;
+        }
+      });
     } else if (n > 0) {
       bb.split(arena, 0, 0);
     }
     lap("  host: apply order, arena");
-    to_reference_layout(arena, nodes);
-    lap("  host: reference layout");
-    blas_root[m] = arena[0].bounds;
+    if (!quiet) blas_root[m] = arena[0].bounds;  // (the same box for both trees of a BLAS: written by one of them)
+    nodes.swap(arena);
     return true;
   };
   for (size_t m = 0; m < blas.size(); ++m) {
+    std::string e1, e2;
     if (builder == RAYCA_BUILDER_SAH) {
+      // two independent trees over the same primitives -- the reference's (tie order + candidate filter) and the one that
+      // is traversed -- built side by side: one's host phases (SoA, order, layout) run under the other's GPU levels
       ref_prims[m] = blas[m].prims;
-      bool ok = build_blas(m, true, ref_prims[m], ref_nodes[m]);   // the reference's tree: tie order + candidate filter
-      lap("reference tree (ranks, leaves)");
-      ok = ok && build_blas(m, false, blas[m].prims, blas[m].nodes);
-      lap("SAH tree");
-      if (!ok) { err = build_err; return RAYCA_ERR_HIP; }
+      bool ok_ref = false;
+      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true); });
+      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false);
+      ref_thread.join();
+      lap("reference tree + SAH tree");
+      if (!ok_ref || !ok) { err = !ok_ref ? e1 : e2; return RAYCA_ERR_HIP; }
     } else {
-      if (!build_blas(m, true, blas[m].prims, blas[m].nodes)) { err = build_err; return RAYCA_ERR_HIP; }
+      if (!build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false)) { err = e1; return RAYCA_ERR_HIP; }
     }
   }
   std::vector<uint32_t> blas_order(blas.size());
@@ -992,10 +1205,10 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     uint32_t slot = 0;
     for (uint32_t b : blas_order) {
       for (uint32_t pi : ref_prims[b]) ref_rank[pi] = slot++;
-      for (const RefNode& rn : ref_nodes[b]) {
-        if (rn.count == 0) continue;  // inner node or the unused slot 1
+      for (const BuildNode& rn : ref_nodes[b]) {
+        if (rn.left >= 0 || rn.count == 0) continue;  // inner node (or the root of an empty BLAS)
         const uint32_t leaf = (uint32_t)(s.ref_leaf_boxes.size() / 8);
-        const float bx[8] = {rn.a.x, rn.a.y, rn.a.z, 0.0f, rn.b.x, rn.b.y, rn.b.z, 0.0f};
+        const float bx[8] = {rn.bounds.a.x, rn.bounds.a.y, rn.bounds.a.z, 0.0f, rn.bounds.b.x, rn.bounds.b.y, rn.bounds.b.z, 0.0f};
         s.ref_leaf_boxes.insert(s.ref_leaf_boxes.end(), bx, bx + 8);
         for (uint32_t i = rn.offset; i < rn.offset + rn.count; ++i) ref_leaf_flat[ref_prims[b][i]] = leaf;
       }
@@ -1027,16 +1240,26 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       base += (uint32_t)bl.prims.size();
     }
     if (base > kLeafFirstMask) { err = "too many primitives for the packed leaf reference (max 33554431)"; return RAYCA_ERR_UNSUPPORTED; }
+    if (on_order_ready) on_order_ready();
     s.root_min = tn[0].bounds.a;
     s.root_max = tn[0].bounds.b;
     uint32_t need = 0;
     s.root_ref = db.emit_tlas(tn, 0, need);
     s.max_depth = need;
+    lap("  binary nodes");
     s.dev_nodes4.clear();
-    WideBuilder wb{s};
-    uint32_t need4 = 0;
-    s.root_ref4 = wb.build(s.root_ref, need4);
-    s.max_depth4 = need4;
+    // the 4-wide collapse reads the binary nodes and writes its own array: it runs next to the fp16 encoding of the binary
+    // nodes below and is joined before its own fp16 copy is made
+    std::thread wide_thread([&s] {
+      WideBuilder wb{s};
+      uint32_t need4 = 0;
+      s.root_ref4 = wb.build(s.root_ref, need4);
+      s.max_depth4 = need4;
+    });
+    struct Joiner {
+      std::thread& t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } wide_joiner{wide_thread};
     s.tie_rank.clear();
     s.ref_leaf_of.clear();
     s.dev_nodes_h.clear();
@@ -1083,6 +1306,9 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           h.right = n.right;
         }
       });
+      lap("  binary nodes, fp16");
+      wide_thread.join();
+      lap("  4-wide nodes (rest)");
       s.dev_nodes4_h.resize(s.dev_nodes4.size());
       parallel_chunks(s.dev_nodes4.size(), [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {

@@ -5,7 +5,10 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rayca_hip.h"
@@ -32,10 +35,16 @@ struct PrimExt {
 static_assert(sizeof(PrimExt) == 256, "PrimExt is 256 B");
 static_assert(offsetof(PrimExt, tangent) == 128, "the second line starts with the tangents");
 
-// BvhNode in the reference's layout (bvh/blas.rs:11-15): root 0, slot 1 unused, children adjacent.
-struct RefNode {
+// A BLAS as the builders leave it: an arena of nodes, root at 0, children by index.  (The reference stores the same tree
+// with children adjacent and slot 1 unused, bvh/blas.rs:11-15,250-256; nothing outside the builder sees that numbering --
+// what is observable is the primitive order and the boxes -- and renumbering half a million nodes cost 23 ms per tree.)
+struct Box {
   F4 a, b;
-  uint32_t offset, count;
+};
+struct BuildNode {
+  Box bounds;
+  uint32_t offset = 0, count = 0;  // primitive range (leaf) -- count == 0 => inner (or the root of an empty BLAS)
+  int32_t left = -1, right = -1;   // indices into the arena
 };
 
 // Device BVH node, 64 B: both children's boxes + packed child references.
@@ -86,7 +95,7 @@ struct HostLight {
 
 struct HostBlas {
   uint32_t model = 0;
-  std::vector<RefNode> nodes;       // reference layout
+  std::vector<BuildNode> nodes;     // arena, root at 0
   std::vector<uint32_t> prims;      // indices into HostScene::prims (post-build order)
 };
 
@@ -101,6 +110,22 @@ struct HostPrim {
   PrimExt ext;
 };
 
+// std::vector<T>::resize without the zero fill: the flatten order array is ~0.5 KB per triangle (126 MB for the atrium), its
+// slots are written exactly once by the threads that fill them, and value-initialising it first costs a single-threaded
+// pass over all of it (page faults included) -- a quarter of scene_create on the benchmark scene
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = DefaultInitAllocator<U>;
+  };
+  template <class U, class... Args>
+  void construct(U* p, Args&&... args) {
+    if constexpr (sizeof...(Args) == 0) ::new (static_cast<void*>(p)) U;
+    else ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
+};
+
 struct HostScene {
   std::vector<Trs> local_trs, world_trs;
   bool has_camera = false;
@@ -111,7 +136,7 @@ struct HostScene {
   std::vector<RaycaTexture> textures;
   std::vector<RaycaImage> images;
   std::vector<uint8_t> image_bytes;
-  std::vector<HostPrim> prims;      // flatten order
+  std::vector<HostPrim, DefaultInitAllocator<HostPrim>> prims;      // flatten order
   std::vector<HostBlas> blas;       // in TLAS blas_nodes order (post-build)
   uint32_t triangle_count = 0, sphere_count = 0;
 
@@ -137,8 +162,16 @@ struct HostScene {
   std::vector<uint32_t> ref_leaf_of;   // slot -> reference leaf index
 };
 
+// Host threads a scene build may use: the CPUs this process may run on (sched_getaffinity), at most 16 (a one-GPU job's
+// share of a node; std::thread::hardware_concurrency() reports the whole machine, and a few hundred threads for a 50 ms
+// phase cost more than they do), RAYCA_HOST_THREADS overrides.
+unsigned host_threads();
+
 // Returns RAYCA_OK or an error code with `err` filled.
-int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err);
+// `on_order_ready` (optional) is called once `out.prims`, `out.world_trs` and `out.prim_order` are final -- before the device
+// node layouts are made -- so that the caller can assemble what only depends on them meanwhile.
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err,
+                         const std::function<void()>& on_order_ready = {});
 
 // Device BLAS builder (bvh_build.hip): the same tree and primitive order as the host builder, built on the GPU.
 // host_scene.cpp does not link HIP; the library registers the function before it builds a scene.
@@ -160,6 +193,7 @@ struct BlasBuildNode {
 using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
 void set_device_blas_builder(BlasBuildFn fn, uint32_t device);
 int32_t selftest_half_rounding(std::string& err);
+int32_t selftest_device_layouts(std::string& err);
 bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
 
 }  // namespace rayca
