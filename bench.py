@@ -345,7 +345,8 @@ def main():
                    "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, ONE collective per frame at frame end, on its own stream"
                                     if world > 1 else "none"),
                    "launched_by": "torch.distributed.run / environment" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py (rayca_amd/launcher.py)" if world > 1 else "single process")},
-        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from three generations up)" if wl_generations >= 3 else "k_generation (generation 0)"),
+        "roofline": {"bound": "hbm", "kernel": ("k_wf_trace / k_wf_shadow (all generations; wavefront engine from three generations up)" if wl_generations >= 3 else
+                                                 ("k_flat_refill (camera rays, lane refill)" if node_format & 1024 else "k_generation (generation 0)")),
                      "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
                      "launch_ms": round(trace_ms, 4), "launches_per_frame": launches_per_frame, "frame_kernel_ms": round(float(np.mean(kms)), 4),
                      "algorithmic_access_rate": {"bytes_per_launch": int(algo_bytes), "GBps": round(algo_rate, 1), "x_hbm_peak": round(algo_rate / HBM_PEAK_GBS, 3),

@@ -6,6 +6,7 @@ for f in sorted(glob.glob(root + "/pass*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "k_generation" in k: k = "k_generation"
+        elif "k_flat_refill" in k: k = "k_flat_refill"
         elif "k_resolve" in k: k = "k_resolve"
         else: continue
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -16,12 +16,13 @@ for wl in ("atrium", "soup"):
         continue
     pmc = json.load(open(s))
     json.dump(pmc, open(os.path.join(out, f"{tag}_{wl}_pmc_summary.json"), "w"), indent=1)
-    g = pmc["k_generation"]
+    kname = "k_flat_refill" if "k_flat_refill" in pmc else "k_generation"   # the soup's camera rays run on the lane-refill kernel
+    g = pmc[kname]
     # MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests
     # at 64 B, i.e. reports half the bytes of 16 B/lane reads -> doubled.  Separate --pmc passes (tests/pmc_passes.sh).
     traffic = int((2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024)
     json.dump({
-        "workload": wl, "kernel": "k_generation (generation 0)", "session": tag,
+        "workload": wl, "kernel": kname, "session": tag,
         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tests/pmc_passes.sh), mean over the dispatches of the run",
         "FETCH_SIZE_KiB": g["FETCH_SIZE"], "WRITE_SIZE_KiB": g["WRITE_SIZE"],
         "correction": "gfx950: FETCH_SIZE x2 for 16 B/lane reads (MI355X_MICROARCH.md, HBM section); uncalibrated for this gather pattern",
@@ -35,7 +36,7 @@ for wl in ("atrium", "soup"):
             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum",
             "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT")
     json.dump({
-        "workload": wl, "kernel": "k_generation (generation 0)", "session": tag,
+        "workload": wl, "kernel": kname, "session": tag,
         "source": "rocprofv3 --pmc, separate passes (tests/pmc_passes.sh): mean over the dispatches of tests/profile_run.py, node format pinned to the one bench.py reports",
         "units": "FETCH_SIZE / WRITE_SIZE in KiB (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2, MI355X_MICROARCH.md HBM section); all others are event counts summed over the chip",
         "counters_per_launch": {k: g[k] for k in keys if k in g},
