@@ -10,7 +10,7 @@ vdir = os.path.join(ROOT, "rayca_amd", "csrc", "variants")
 desc = flatten(scenes.atrium_scene())
 W, H = 1920, 1080
 cases = [("pt3 general", Config(max_depth=3), abi.ENGINE_GENERAL), ("raytracer 2", Config(integrator=I.Raytracer, max_depth=2), abi.ENGINE_AUTO),
-         ("pt3 ls4", Config(max_depth=3, light_samples=4), abi.ENGINE_AUTO), ("roulette", Config(russian_roulette=True), abi.ENGINE_AUTO)]
+         ("pt3 ls4", Config(max_depth=3, light_samples=4), abi.ENGINE_AUTO)]
 dss = {}
 for n in names:
     path = os.path.join(ROOT, "rayca_amd", "csrc", "librayca_hip.so") if n == "main" else os.path.join(vdir, f"librayca_{n}.so")
