@@ -539,6 +539,8 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_sm
 
 }  // namespace
 
+const void* gpu_builder_any_kernel() { return reinterpret_cast<const void*>(k_build_small); }
+
 // BlasBuildFn: see host_scene.hpp
 bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err) {
   const uint32_t n = in.count;

@@ -195,5 +195,6 @@ void set_device_blas_builder(BlasBuildFn fn, uint32_t device);
 int32_t selftest_half_rounding(std::string& err);
 int32_t selftest_device_layouts(std::string& err);
 bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
+const void* gpu_builder_any_kernel();  // host stub of one kernel of bvh_build.hip (to load that code object ahead of time)
 
 }  // namespace rayca
