@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
       const bool found = trace<ORDERED, FAST, SPH, WIDE, SPILL, STATS, HALF, kLeaveK>(sc, ray, t_stop, stack, hit, cnt);
       if (!in_shadow) {
         if (!found) {
-          if (FUSED) direct = black() + black();  // unwrap_or(BLACK), color += it
+          if (FUSED) direct = black() + black();  // unwrap_or(BLACK), color += it   (path frames: k_resolve's `prev + c`, c = BLACK)
           else pb.state[slot] = kVertexNone;
           live = false;
         } else {
@@ -111,8 +111,11 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
             }
             live = false;
           } else if (collect_emissive && emissive) {  // pathtracer.rs:83-87
-            pb.direct[slot] = as_f4(color);
-            pb.state[slot] = kVertexEmissive;
+            if (FUSED) direct = black() + color;  // k_resolve: L = the emissive colour, acc = BLACK + L
+            else {
+              pb.direct[slot] = as_f4(color);
+              pb.state[slot] = kVertexEmissive;
+            }
             live = false;
           } else {
             in_shadow = true;  // enter the NEE loop (possibly empty)
@@ -158,7 +161,19 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
         }
       }
     }
-    if (FUSED) {
+    if (FUSED && MODE == kModePath) {
+      // One generation, one sample (RAYCA_FUSE_PATH1): no records, no k_resolve -- the vertex's value is folded here the way
+      // k_resolve folds a single depth: L = direct + (BLACK + (BLACK [+ 0]) / light_samples), pixel = BLACK + L.
+      if (tail) {
+        if (PARK) direct = as_color(ctx_slot[6 * kBlock]);
+        const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
+        Color indirect = black();
+        if (depth < limit) indirect = indirect + black() / (float)fp.light_samples;  // kVertexLit without a child: li stays BLACK
+        direct = black() + (direct + indirect);
+      }
+      n_shadow += (uint32_t)__popcll(__ballot(tail)) * nee_lights * fp.light_samples;
+      if (has_pixel) finalize_pixel(fp, direct, p, rgba8, rgba32f);
+    } else if (FUSED) {
       if (has_pixel) finalize_pixel(fp, direct, p, rgba8, rgba32f);
     } else if (MODE == kModePath) {
       bool want_bounce = false;
