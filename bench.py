@@ -186,6 +186,7 @@ def main():
         def __init__(self, B):
             self.B = B
             self.counter = 0
+            self.issue = {}   # (send buffer, slot, context) -> prepared render call
             self.gatherer = FrameGatherer(H, W, args.band_rows, gather_dev, batch=B)
             self.sends = [torch.zeros((B, self.gatherer.max_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
             self.frames = [torch.empty((B, H, W, 4), dtype=torch.uint8, device=gather_dev) if rank == 0 else None for _ in range(2)]
@@ -213,9 +214,12 @@ def main():
             st_c = streams[c]
             b, k = i % self.B, (i // self.B) % 2
             buf = self.sends[k][b, :my_rows]
+            issue = self.issue.get((k, b, c))
+            if issue is None:
+                issue = self.issue[(k, b, c)] = ds.prepare_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, context=c)
             with torch.cuda.stream(st_c):
                 st_c.wait_event(self.ev_gather[k])   # the previous gather out of this send buffer has finished
-                ds.render_device(cfg, W, H, buf.data_ptr(), 0, tile=tile, stream=st_c.cuda_stream, context=c)
+                issue()
                 self.ev_render[k][b].record(st_c)
             return self.flush(k, self.B) if b == self.B - 1 else None
 
@@ -231,12 +235,12 @@ def main():
 
         def __init__(self):
             self.counter = 0
+            self.issue = [ds.prepare_device(cfg, W, H, outs[c].data_ptr(), 0, tile=tile, stream=streams[c].cuda_stream, context=c) for c in range(F)]
 
         def step(self):
             c = self.counter % F
             self.counter += 1
-            with torch.cuda.stream(streams[c]):
-                ds.render_device(cfg, W, H, outs[c].data_ptr(), 0, tile=tile, stream=streams[c].cuda_stream, context=c)
+            self.issue[c]()
             return outs[c]
 
         def drain(self):

@@ -255,7 +255,14 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
 
 // Fold the per-depth records in the reference's order (pathtracer.rs:23-66,94-105):
 //   L_g = direct_g + (BLACK + (BLACK + (factor_g * L_{g+1}) * weight) / light_samples)
-__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers pb, uint32_t depths, float4* accum, uint8_t* rgba8, float4* rgba32f) {
+// `clear` (optional): `clear_words` dwords zeroed by the first block -- the work counters of this frame context, which the
+// generation kernel in front of this one has finished with (same stream), so that the next frame of the context needs no
+// memset launch of its own (a frame is three launches then instead of four: what a rank's share of a frame costs on the
+// host is what limits an 8-GPU run).
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, PathBuffers pb, uint32_t depths, float4* accum, uint8_t* rgba8, float4* rgba32f,
+                                                    uint32_t* clear, uint32_t clear_words) {
+  if (clear && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < clear_words; i += blockDim.x) clear[i] = 0u;
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= pb.npix) return;
   bool some = false;

@@ -1,0 +1,47 @@
+"""What one rank of an N-GPU run costs per frame on THIS GPU: render part 0 of `parts` (bands of 8 rows) with F frames in
+flight, optionally followed by a per-frame RCCL gather on a 1-rank group (the collective's launch + Python cost without the
+wire and without the other ranks' skew).  usage: python tests/gpu_rank_share_probe.py [parts ...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+import numpy as np
+import torch
+import torch.distributed as dist
+from rayca_amd import Config, DeviceScene, flatten, scenes, abi
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+cfg, W, H = Config(max_depth=1), 1920, 1080
+ds = DeviceScene(flatten(scenes.atrium_scene()), cfg, builder=abi.BUILDER_SAH)
+parts_list = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+for parts in parts_list:
+    tile = (0, parts, 8)
+    rows = ds.tile_rows(tile, H)
+    for F in [int(x) for x in os.environ.get("RAYCA_PROBE_F", "2,4").split(",")]:
+        streams = [torch.cuda.Stream(dev) for _ in range(F)]
+        comm = torch.cuda.Stream(dev)
+        sends = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
+        recv = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev)]
+        ev = [torch.cuda.Event() for _ in range(F)]
+        for i in range(F):   # contexts warm, node format decided
+            for _ in range(10):
+                ds.render_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i, want_stats=True)
+        issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i) for i in range(F)]
+        for gather in (False, True):
+            K = 200
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(K):
+                i = k % F
+                issue[i]()
+                ev[i].record(streams[i])
+                if gather:
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(ev[i])
+                        dist.gather(sends[i], recv, dst=0)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / K * 1e3
+            print(f"parts {parts} ({rows} rows) F={F} gather={'per frame' if gather else 'none':9s}: {ms:.4f} ms/frame  -> {parts}-GPU frame rate x{0.4475 / ms:.2f} of one GPU's", flush=True)
+dist.destroy_process_group()
