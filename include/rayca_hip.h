@@ -350,7 +350,9 @@ typedef struct RaycaStats {
    * generations did, bits 2 / 3 = the same for fp16 node boxes, bit 8 = this was a calibration frame (the scene
    * is still timing the formats), bit 9 = a calibration frame of the camera-ray kernel choice (Flat frames: fused
    * generation kernel or lane-refill kernel, timed once the format is settled), bit 10 = this frame's camera rays ran on
-   * the lane-refill kernel */
+   * the lane-refill kernel, bit 11 = the scene's 4-wide / fp16 node formats were still being made when this frame was
+   * issued (a thread started by rayca_hip_scene_create encodes and uploads them; until then frames traverse the binary
+   * f32 nodes and nothing is timed -- same pixels either way) */
   uint32_t node_format;
 } RaycaStats;
 
@@ -362,7 +364,8 @@ typedef struct RaycaSceneInfo {
   uint32_t max_depth;       /* traversal stack entries per ray (LDS) the device BVH needs */
   uint32_t light_count;
   uint64_t device_bytes;    /* HBM resident for this scene */
-  float build_ms;           /* rayca_hip_scene_create of this scene: flatten + BVH build + device layout + upload */
+  float build_ms;           /* rayca_hip_scene_create of this scene: flatten + BVH build + binary-node layout + upload,
+                               i.e. until a frame can be rendered (the other node formats follow on their own thread) */
   float runtime_init_ms;    /* what that call spent before it: HIP context + code object load, ~0 except for a
                                process's first scene on a device */
 } RaycaSceneInfo;
@@ -392,6 +395,12 @@ int32_t rayca_hip_scene_create(const RaycaSceneDesc* desc, const RaycaConfig* cf
                                const RaycaBuildOptions* opts, RaycaScene** out);
 int32_t rayca_hip_scene_destroy(RaycaScene* scene);
 int32_t rayca_hip_scene_info(const RaycaScene* scene, RaycaSceneInfo* out);
+/* rayca_hip_scene_create returns as soon as frames can be rendered -- on the binary f32 nodes; the 4-wide and fp16
+ * node formats a RAYCA_BUILDER_SAH scene times against them are encoded and uploaded by a thread of their own, and
+ * frames pick them up when they are there (RaycaStats.node_format bit 11).  This waits for that thread: for hosts
+ * that want every frame from the first on to be eligible for every format (benchmarks, tests).  Never required:
+ * the pixels are the same with every format.  No reference counterpart. */
+int32_t rayca_hip_scene_finish(RaycaScene* scene);
 
 /* The second half of SoftRenderer::draw (scene.rs:101-150): the pixel loop.  Renders
  * width x height with camera_draw_infos[0] and writes RGBA8 (rgba8.rs:75-84) and/or the

@@ -348,6 +348,8 @@ def bind_product_signatures(lib):
     lib.rayca_hip_scene_destroy.argtypes = [C.c_void_p]
     lib.rayca_hip_scene_info.restype = C.c_int32
     lib.rayca_hip_scene_info.argtypes = [C.c_void_p, P(RaycaSceneInfo)]
+    lib.rayca_hip_scene_finish.restype = C.c_int32
+    lib.rayca_hip_scene_finish.argtypes = [C.c_void_p]
     lib.rayca_hip_render.restype = C.c_int32
     lib.rayca_hip_render.argtypes = [C.c_void_p, P(RaycaConfig), C.c_uint32, C.c_uint32, P(RaycaRenderOptions),
                                      C.c_void_p, C.c_void_p, P(RaycaStats)]
@@ -371,7 +373,7 @@ def bind_product_signatures(lib):
 
 PRODUCT_SYMBOLS = [
     "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_selftest", "rayca_hip_last_error", "rayca_hip_config_default",
-    "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_info", "rayca_hip_render",
+    "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_info", "rayca_hip_scene_finish", "rayca_hip_render",
     "rayca_hip_render_device", "rayca_hip_tile_rows", "rayca_hip_trace_rays",
     "rayca_hip_scene_primitive_order", "rayca_hip_render_multi", "rayca_hip_rccl_status",
 ]

@@ -21,6 +21,7 @@
 #include <thread>
 
 #include <cfloat>
+#include <cstddef>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -39,12 +40,17 @@ constexpr uint32_t kChunk = 4096;
 constexpr uint32_t kBinWords = 3 * 64 * 7;  // per node: count + min xyz + max xyz for 64 bins on 3 axes
 constexpr uint32_t kSeq = 16;  // subtrees of at most this many primitives are finished by ONE thread (k_build_small)
 
+// The host builder's BuildNode, field for field (host_scene.hpp: two points with w = 1, range, children): the finished
+// array is copied straight into the host arena.
 struct DNode {
-  float a[3], b[3];
+  float a[4], b[4];
   uint32_t offset, count;
   int32_t left, right;
-  uint32_t big;  // slot of this node's bins in BuildState::gbins when it was binned by k_bin_big, else RAYCA_NONE
 };
+static_assert(sizeof(DNode) == sizeof(BuildNode) && offsetof(DNode, b) == offsetof(BuildNode, bounds) + sizeof(F4) &&
+              offsetof(DNode, offset) == offsetof(BuildNode, offset) && offsetof(DNode, count) == offsetof(BuildNode, count) &&
+              offsetof(DNode, left) == offsetof(BuildNode, left) && offsetof(DNode, right) == offsetof(BuildNode, right),
+              "DNode is downloaded into a std::vector<BuildNode>");
 
 struct BuildState {
   const float* cent[3];  // centroid, SoA, by primitive id
@@ -56,6 +62,7 @@ struct BuildState {
   uint32_t* hole_pos;    // per node range: position of the k-th hole
   uint32_t* filler_pos;  // per node range: position of the k-th filler
   DNode* nodes;
+  uint32_t* big;         // per node: slot of its bins in gbins when it is binned by k_bin_big, else RAYCA_NONE
   uint32_t* node_count;
   uint32_t* small_nodes;  // roots of subtrees left to k_build_small, and their levels
   uint32_t* small_levels;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chun
   const uint32_t begin = job.y * kChunk, end = min(nd.count, begin + kChunk);
   bin_range(st, nd, valid, s_cnt, s_min, s_max, s_pos, begin, end);
   __syncthreads();
-  uint32_t* g = st.gbins + (size_t)nd.big * kBinWords;
+  uint32_t* g = st.gbins + (size_t)st.big[job.x] * kBinWords;
   for (uint32_t i = threadIdx.x; i < 3 * 64; i += kB) {
     const uint32_t a = i / 64, b = i % 64;
     if (s_cnt[a][b] == 0) continue;
@@ -200,8 +207,9 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
   __syncthreads();
   bool valid[3];
   for (int a = 0; a < 3; ++a) valid[a] = nd.a[a] != nd.b[a];
-  if (nd.big != RAYCA_NONE) {  // binned by k_bin_big: fetch
-    const uint32_t* g = st.gbins + (size_t)nd.big * kBinWords;
+  const uint32_t nd_big = st.big[node_id];
+  if (nd_big != RAYCA_NONE) {  // binned by k_bin_big: fetch
+    const uint32_t* g = st.gbins + (size_t)nd_big * kBinWords;
     for (uint32_t i = tid; i < 3 * 64; i += kB) {
       const uint32_t a = i / 64, b = i % 64;
       s_cnt[a][b] = g[i * 7];
@@ -376,13 +384,15 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
       l.a[c] = dec(s_red[0][0][c]); l.b[c] = dec(s_red[0][1][c]);
       r.a[c] = dec(s_red[1][0][c]); r.b[c] = dec(s_red[1][1][c]);
     }
+    l.a[3] = l.b[3] = r.a[3] = r.b[3] = 1.0f;
     l.offset = off; l.count = nl; l.left = l.right = -1;
     r.offset = off + nl; r.count = n - nl; r.left = r.right = -1;
-    l.big = nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE;
-    r.big = n - nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE;
+    const uint32_t big2[2] = {nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE, n - nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE};
+    st.big[base] = big2[0];
+    st.big[base + 1] = big2[1];
     for (uint32_t c = 0; c < 2; ++c) {
       const DNode& ch = c ? r : l;
-      if (ch.big == RAYCA_NONE) continue;
+      if (big2[c] == RAYCA_NONE) continue;
       const uint32_t nch = (ch.count + kChunk - 1) / kChunk;
       const uint32_t at = atomicAdd(st.chunk_count, nch);
       for (uint32_t k = 0; k < nch; ++k) next_chunks[at + k] = make_uint2(base + c, k);
@@ -514,8 +524,10 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_sm
         r.a[c] = fminf(r.a[c], mn[c][k]);
         r.b[c] = fmaxf(r.b[c], mx[c][k]);
       }
-    l.offset = nd.offset; l.count = nl; l.left = l.right = -1; l.big = RAYCA_NONE;
-    r.offset = nd.offset + nl; r.count = nr; r.left = r.right = -1; r.big = RAYCA_NONE;
+    l.a[3] = l.b[3] = r.a[3] = r.b[3] = 1.0f;
+    l.offset = nd.offset; l.count = nl; l.left = l.right = -1;
+    r.offset = nd.offset + nl; r.count = nr; r.left = r.right = -1;
+    st.big[base] = st.big[base + 1] = RAYCA_NONE;
     st.nodes[base] = l;
     st.nodes[base + 1] = r;
     st.nodes[node_id].left = (int32_t)base;
@@ -542,7 +554,7 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_sm
 const void* gpu_builder_any_kernel() { return reinterpret_cast<const void*>(k_build_small); }
 
 // BlasBuildFn: see host_scene.hpp
-bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err) {
+bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err) {
   const uint32_t n = in.count;
   // One device allocation, carved up here, and a stream of its own: a RAYCA_BUILDER_SAH scene builds two trees at the same
   // time from two host threads (host_scene.cpp), and each build is a chain of small launches with a counter read-back per
@@ -580,7 +592,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   size_t off_f[9], off_u[9];
   for (int i = 0; i < 9; ++i) off_f[i] = reserve(sizeof(float) * n);
   for (int i = 0; i < 9; ++i) off_u[i] = reserve(sizeof(uint32_t) * ((size_t)n + 2));
-  const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
+  const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_big = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
   const size_t off_chunks[2] = {reserve((size_t)max_chunks * sizeof(uint2)), reserve((size_t)max_chunks * sizeof(uint2))};
   HB_TRY(hipMalloc(&pool, pool_bytes));
   char* base = static_cast<char*>(pool);
@@ -601,6 +613,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   st.small_nodes = u[7];
   st.small_levels = u[8];
   st.nodes = reinterpret_cast<DNode*>(base + off_nodes);
+  st.big = reinterpret_cast<uint32_t*>(base + off_big);
   st.node_count = reinterpret_cast<uint32_t*>(base + off_counts);
   st.chunk_count = st.node_count + 3;
   st.slot_count = st.node_count + 4;
@@ -619,9 +632,11 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     root.a[c] = in.root_min[c];
     root.b[c] = in.root_max[c];
   }
+  root.a[3] = root.b[3] = 1.0f;
   root.offset = 0; root.count = n; root.left = root.right = -1;
-  root.big = n > kBig ? 0u : RAYCA_NONE;
+  const uint32_t root_big = n > kBig ? 0u : RAYCA_NONE;
   HB_TRY(hipMemcpyAsync(st.nodes, &root, sizeof root, hipMemcpyHostToDevice, stream));
+  HB_TRY(hipMemcpyAsync(st.big, &root_big, sizeof root_big, hipMemcpyHostToDevice, stream));
   const uint32_t init[5] = {1u, 0u, 0u, 0u, 0u};
   HB_TRY(hipMemcpyAsync(st.node_count, init, sizeof init, hipMemcpyHostToDevice, stream));
   const uint32_t zero = 0;
@@ -683,33 +698,12 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   uint32_t node_count = 0;
   HB_TRY(hipMemcpyAsync(&node_count, st.node_count, 4, hipMemcpyDeviceToHost, stream));
   HB_TRY(hipStreamSynchronize(stream));
-  std::vector<DNode, DefaultInitAllocator<DNode>> nodes(node_count);
-  HB_TRY(hipMemcpyAsync(nodes.data(), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost, stream));
+  arena.resize(node_count);   // DNode == BuildNode (asserted above): no conversion pass
   order.resize(n);
+  HB_TRY(hipMemcpyAsync(static_cast<void*>(arena.data()), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost, stream));
   HB_TRY(hipMemcpyAsync(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream));
   HB_TRY(hipStreamSynchronize(stream));
-  arena.resize(node_count);
-  {
-    const unsigned nt = std::max(1u, std::min(host_threads() / 2u, node_count / 65536u + 1u));
-    auto convert = [&](uint32_t b, uint32_t e) {
-      for (uint32_t i = b; i < e; ++i) {
-        for (int c = 0; c < 3; ++c) {
-          arena[i].a[c] = nodes[i].a[c];
-          arena[i].b[c] = nodes[i].b[c];
-        }
-        arena[i].offset = nodes[i].offset;
-        arena[i].count = nodes[i].count;
-        arena[i].left = nodes[i].left;
-        arena[i].right = nodes[i].right;
-      }
-    };
-    std::vector<std::thread> pool;
-    const uint32_t per = (node_count + nt - 1) / nt;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(convert, std::min(node_count, t * per), std::min(node_count, (t + 1) * per));
-    convert(0, std::min(node_count, per));
-    for (std::thread& th : pool) th.join();
-  }
-  lap("download + convert");
+  lap("download");
   cleanup();
   lap("free");
   return true;

@@ -334,8 +334,9 @@ void tlas_split(std::vector<TNode>& tn, int32_t self, std::vector<uint32_t>& bla
   }
 }
 
-// double -> IEEE half, rounded toward -inf (up == false) or +inf (up == true); NaN for NaN
-uint16_t to_half_directed(double v, bool up) {
+// double -> IEEE half, rounded toward -inf (up == false) or +inf (up == true); NaN for NaN.  The arithmetic statement of
+// the rounding; the encoder uses the bit form below, the self-test holds the two against each other.
+uint16_t to_half_directed_ref(double v, bool up) {
   if (v != v) return 0x7E00u;
   const bool neg = std::signbit(v);
   double a = std::fabs(v);
@@ -361,6 +362,23 @@ uint16_t to_half_directed(double v, bool up) {
     if (e > 15) return (uint16_t)(sign | 0x7C00u);
   }
   return (uint16_t)(sign | ((uint16_t)(e + 15) << 10) | ((uint16_t)r - 1024u));
+}
+
+// The same on the bits of the double: a value in the normal range of a half keeps its top ten mantissa bits, and moves one
+// unit away from zero when anything was cut off and the direction asks for it (the carry runs into the exponent, and out
+// of the largest one into infinity, as it should).  Everything else -- zero, subnormal halves, overflow, inf, NaN -- takes
+// the arithmetic form.  (A scene build converts twelve of these per node, twice over.)
+inline uint16_t to_half_directed(double v, bool up) {
+  uint64_t bits;
+  std::memcpy(&bits, &v, sizeof bits);
+  const uint64_t mag = bits & 0x7FFFFFFFFFFFFFFFull;
+  const int e = (int)(mag >> 52) - 1023;
+  if (e < -14 || e > 15) return to_half_directed_ref(v, up);
+  const bool neg = (bits >> 63) != 0;
+  const uint64_t man = mag & 0x000FFFFFFFFFFFFFull;
+  uint32_t h = ((uint32_t)(e + 15) << 10) | (uint32_t)(man >> 42);
+  if ((neg ? !up : up) && (man & 0x3FFFFFFFFFFull)) ++h;
+  return (uint16_t)((neg ? 0x8000u : 0u) | h);
 }
 
 // ---- device layout -------------------------------------------------------------------------------
@@ -851,6 +869,22 @@ int32_t selftest_half_rounding(std::string& err) {
       if (lo != v || hi != w) return fail("bracket is not the two neighbours", x);
     }
   }
+  // the bit form against the arithmetic form: every binade a half can hold and the ones either side, both signs, values
+  // on, just above and just below a half's grid
+  uint64_t lcg = 0x9E3779B97F4A7C15ull;
+  for (int e = -30; e <= 20; ++e)
+    for (int i = 0; i < 4096; ++i) {
+      lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      uint64_t man = lcg >> 12;
+      if (i % 4 == 1) man &= ~0x3FFFFFFFFFFull;                   // exactly representable
+      if (i % 4 == 2) man = (man & ~0x3FFFFFFFFFFull) | 1ull;      // one ulp of the double above
+      if (i % 4 == 3) man |= 0x3FFFFFFFFFFull;                     // just below the next
+      const uint64_t bits = ((uint64_t)((i >> 2) & 1) << 63) | ((uint64_t)(e + 1023) << 52) | man;
+      double x;
+      std::memcpy(&x, &bits, sizeof x);
+      for (const bool up : {false, true})
+        if (to_half_directed(x, up) != to_half_directed_ref(x, up)) return fail("bit form differs from the arithmetic form", x);
+    }
   if (to_half_directed(1e6, true) != 0x7C00u || to_half_directed(1e6, false) != 0x7BFFu) return fail("overflow", 1e6);
   if (to_half_directed(-1e6, false) != 0xFC00u || to_half_directed(-1e6, true) != 0xFBFFu) return fail("overflow", -1e6);
   if (to_half_directed(1e-9, true) != 0x0001u || to_half_directed(1e-9, false) != 0x0000u) return fail("underflow", 1e-9);
@@ -862,7 +896,96 @@ void set_device_blas_builder(BlasBuildFn fn, uint32_t device) {
   g_device_ordinal = device;
 }
 
-int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err, const std::function<void()>& on_order_ready) {
+// The three node formats next to the binary f32 one (RAYCA_BUILDER_SAH scenes): the same tree collapsed to 4-wide nodes, and
+// both with fp16 steering boxes.  Reads `s.dev_nodes`, writes `dev_nodes4`, `dev_nodes_h`, `dev_nodes4_h` and their scalars; the
+// library runs it on a thread of its own while the first frames are already traversing the binary nodes.
+void finish_node_formats(HostScene& s) {
+  if (!s.other_formats_wanted) return;
+  static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[rayca build] %-28s %8.1f ms\n", what, std::chrono::duration<float, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
+  // the 4-wide collapse reads the binary nodes and writes its own array: it runs next to the fp16 encoding of the binary
+  // nodes below and is joined before its own fp16 copy is made
+  std::thread wide_thread([&s] {
+    WideBuilder wb{s};
+    uint32_t need4 = 0;
+    s.root_ref4 = wb.build(s.root_ref, need4);
+    s.max_depth4 = need4;
+  });
+  struct Joiner {
+    std::thread& t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+  } wide_joiner{wide_thread};
+  // fp16 steering boxes: centre of the scene box, power-of-two scale that maps the half extent to <= 2^14
+  float half_extent = 0.0f;
+  const float lo3[3] = {s.root_min.x, s.root_min.y, s.root_min.z}, hi3[3] = {s.root_max.x, s.root_max.y, s.root_max.z};
+  for (int c = 0; c < 3; ++c) {
+    s.half_center[c] = 0.5f * (lo3[c] + hi3[c]);
+    if (!(s.half_center[c] == s.half_center[c]) || std::fabs(s.half_center[c]) > 1e30f) s.half_center[c] = 0.0f;
+    half_extent = std::max(half_extent, std::max(std::fabs(hi3[c] - s.half_center[c]), std::fabs(lo3[c] - s.half_center[c])));
+  }
+  int k = 0;
+  if (half_extent > 0.0f && half_extent < 1e30f) {
+    (void)std::frexp(half_extent * 1.0009765625f, &k);  // half_extent (+ padding) < 2^k
+    k = 14 - k;
+  }
+  k = std::max(-100, std::min(100, k));
+  s.half_scale = std::ldexp(1.0f, k);
+  auto cv = [&](float x, int axis, bool up) -> uint16_t {
+    // only NaNs are unenterable here; the "nowhere" slots are recognised box by box below.  Finite coordinates beyond
+    // the fp16 range saturate OUTWARD (to_half_directed: max -> +inf, min -> -inf), so the box stays conservative
+    // and the frame cannot depend on the node format chosen, whatever the scene's extent.
+    if (!(x == x)) return 0x7E00u;
+    return to_half_directed(((double)x - (double)s.half_center[axis]) * (double)s.half_scale, up);
+  };
+  s.dev_nodes_h.resize(s.dev_nodes.size());
+  parallel_chunks(s.dev_nodes.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const DevNode& n = s.dev_nodes[i];
+      DevNodeH& h = s.dev_nodes_h[i];
+      // q: l.min xyz, l.max xyz, r.min xyz, r.max xyz
+      for (int j = 0; j < 12; ++j) h.h[j] = cv(n.q[j], j % 3, (j / 3) & 1);
+      // an inverted (empty) box and the zero-size "nowhere" box of an unused slot must stay unenterable after
+      // outward rounding
+      for (int side = 0; side < 2; ++side) {
+        bool nowhere = true;
+        for (int j = 0; j < 6; ++j) nowhere = nowhere && n.q[side * 6 + j] == kNowhere;
+        if (nowhere || !(n.q[side * 6] <= n.q[side * 6 + 3]))
+          for (int j = 0; j < 6; ++j) h.h[side * 6 + j] = 0x7E00u;
+      }
+      h.left = n.left;
+      h.right = n.right;
+    }
+  });
+  lap("  binary nodes, fp16");
+  wide_thread.join();
+  lap("  4-wide nodes (rest)");
+  s.dev_nodes4_h.resize(s.dev_nodes4.size());
+  parallel_chunks(s.dev_nodes4.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const DevNode4& n = s.dev_nodes4[i];
+      DevNode4H& h = s.dev_nodes4_h[i];
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 4; ++c) {
+          bool empty = !(n.lo[0][c] <= n.hi[0][c]);
+          if (n.lo[0][c] == kNowhere && n.hi[0][c] == kNowhere && n.lo[1][c] == kNowhere && n.hi[1][c] == kNowhere && n.lo[2][c] == kNowhere &&
+              n.hi[2][c] == kNowhere)
+            empty = true;  // unused slot (WideBuilder)
+          h.lo[a][c] = empty ? 0x7E00u : cv(n.lo[a][c], a, false);
+          h.hi[a][c] = empty ? 0x7E00u : cv(n.hi[a][c], a, true);
+        }
+      for (int c = 0; c < 4; ++c) h.child[c] = n.child[c];
+    }
+  });
+  lap("  4-wide nodes, fp16");
+}
+
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& s, std::string& err, const BuildHooks& hooks) {
   // RAYCA_BUILD_TIMING=1: phase times of the host build on stderr
   static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
@@ -965,6 +1088,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         total += d.primitives[pi].geometry == RAYCA_GEOMETRY_SPHERE ? 1u : d.primitives[pi].index_count / 3u;
     }
     s.prims.reserve(total);
+    s.ext.reserve(total);
   }
   for (size_t m = 0; m < models.size(); ++m) {
     blas[m].model = models[m];
@@ -984,12 +1108,15 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           hp.material = p.material;
           hp.center = point3(p.sphere_center[0], p.sphere_center[1], p.sphere_center[2]);
           hp.radius = p.sphere_radius;
-          hp.ext.material = p.material;
-          hp.ext.kind = hp.kind;
-          hp.ext.node = node;
+          PrimExt ext;
+          std::memset(&ext, 0, sizeof ext);
+          ext.material = p.material;
+          ext.kind = hp.kind;
+          ext.node = node;
           hp.src = (uint32_t)s.prims.size();
           blas[m].prims.push_back(hp.src);
           s.prims.push_back(hp);
+          s.ext.push_back(ext);
           s.sphere_count++;
           continue;
         }
@@ -1000,6 +1127,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         for (uint32_t at = 0; at < ntri; at += 8192)  // pieces, so that one huge mesh still feeds every thread
           jobs.push_back(TriJob{node, pi, at, first_out + at, std::min<uint32_t>(8192u, ntri - at), tangent_matrix, normal_matrix});
         s.prims.resize((size_t)first_out + ntri);
+        s.ext.resize((size_t)first_out + ntri);
         {
           const size_t at = blas[m].prims.size();
           blas[m].prims.resize(at + ntri);  // (geometric growth: a model of many small meshes must not reallocate per mesh)
@@ -1021,17 +1149,20 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         hp.kind = RAYCA_GEOMETRY_TRIANGLE_MESH;
         hp.node = node;
         hp.material = l.material;
+        PrimExt ext;
+        std::memset(&ext, 0, sizeof ext);
         for (int k = 0; k < 3; ++k) {
           hp.p[k] = tri[t][k];
-          set_ext(hp.ext, k, white(), normal, vec3(0, 0, 0), vec3(0, 0, 0), F2{0, 0});
+          set_ext(ext, k, white(), normal, vec3(0, 0, 0), vec3(0, 0, 0), F2{0, 0});
         }
         hp.centroid = ((to_vec(hp.p[0]) + to_vec(hp.p[1])) + to_vec(hp.p[2])) * 0.3333f;
-        hp.ext.material = l.material;
-        hp.ext.kind = hp.kind;
-        hp.ext.node = node;
+        ext.material = l.material;
+        ext.kind = hp.kind;
+        ext.node = node;
         hp.src = (uint32_t)s.prims.size();
         blas[m].prims.push_back(hp.src);
         s.prims.push_back(hp);
+        s.ext.push_back(ext);
         s.triangle_count++;
       }
     }
@@ -1055,7 +1186,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           hp.material = p.material;
           hp.center = point3(0, 0, 0);
           hp.radius = 0.0f;
-          std::memset(&hp.ext, 0, sizeof hp.ext);
+          PrimExt& ext = s.ext[job.first_out + t];
+          std::memset(&ext, 0, sizeof ext);
           const char* problem = nullptr;
           for (int k = 0; k < 3; ++k) {
             uint32_t idx;
@@ -1068,16 +1200,16 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
             const F4 tan = d.tangents ? vec3(d.tangents[3 * v], d.tangents[3 * v + 1], d.tangents[3 * v + 2]) : vec3(0, 0, 0);
             const F4 bit = d.bitangents ? vec3(d.bitangents[3 * v], d.bitangents[3 * v + 1], d.bitangents[3 * v + 2]) : vec3(0, 0, 0);
             const F2 uv = d.uvs ? F2{d.uvs[2 * v], d.uvs[2 * v + 1]} : F2{0, 0};
-            set_ext(hp.ext, k, c, mat3_apply(job.normal_matrix, nrm), mat3_apply(job.tangent_matrix, tan), mat3_apply(job.tangent_matrix, bit), uv);
+            set_ext(ext, k, c, mat3_apply(job.normal_matrix, nrm), mat3_apply(job.tangent_matrix, tan), mat3_apply(job.tangent_matrix, bit), uv);
           }
           if (problem) {
             if (!failed.exchange(1)) first_error = problem;
             return;
           }
           hp.centroid = ((to_vec(hp.p[0]) + to_vec(hp.p[1])) + to_vec(hp.p[2])) * 0.3333f;  // triangle.rs:59-63
-          hp.ext.material = p.material;
-          hp.ext.kind = hp.kind;
-          hp.ext.node = job.node;
+          ext.material = p.material;
+          ext.kind = hp.kind;
+          ext.node = job.node;
           hp.src = job.first_out + t;
         }
       }
@@ -1090,10 +1222,21 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     if (failed.load()) { err = first_error ? first_error : "bad triangle data"; return RAYCA_ERR_BAD_ARG; }
   }
   lap("flatten primitives");
+  s.tris.resize(s.prims.size() * 9);
   parallel_chunks(s.prims.size(), [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; ++i) cache_world(s.prims[i], s.world_trs[s.prims[i].node]);
+    for (size_t i = b; i < e; ++i) {
+      HostPrim& p = s.prims[i];
+      cache_world(p, s.world_trs[p.node]);
+      float* tv = &s.tris[i * 9];
+      for (int k = 0; k < 3; ++k) {
+        tv[3 * k + 0] = p.wp[k].x;
+        tv[3 * k + 1] = p.wp[k].y;
+        tv[3 * k + 2] = p.wp[k].z;
+      }
+    }
   });
   lap("world-space vertices, boxes");
+  if (hooks.on_prims_ready) hooks.on_prims_ready();
 
   // ---- Tlas::new: one BLAS per model ------------------------------------------------------------
   const unsigned hw = host_threads();
@@ -1108,7 +1251,24 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   const BlasBuildFn device_builder = g_device_builder;
   const uint32_t device_ordinal = g_device_ordinal;
   std::mutex lap_mu;
-  auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<BuildNode>& nodes, std::string& build_err, bool quiet) {
+  // what the device builder reads: world centroids and boxes of a BLAS's primitives, SoA, in the BLAS's initial order (the
+  // two trees of a RAYCA_BUILDER_SAH scene start from the same order and share one copy)
+  using Soa = std::vector<float, DefaultInitAllocator<float>>;   // nine planes of n floats, one block
+  auto make_soa = [&](const std::vector<uint32_t>& order, Soa& soa) {
+    const size_t n = order.size();
+    soa.resize(9 * n);
+    float* const q = soa.data();
+    parallel_chunks(n, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const HostPrim& p = s.prims[order[i]];
+        q[i] = p.wcentroid.x; q[n + i] = p.wcentroid.y; q[2 * n + i] = p.wcentroid.z;
+        q[3 * n + i] = p.wmin.x; q[4 * n + i] = p.wmin.y; q[5 * n + i] = p.wmin.z;
+        q[6 * n + i] = p.wmax.x; q[7 * n + i] = p.wmax.y; q[8 * n + i] = p.wmax.z;
+      }
+    });
+  };
+  auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<BuildNode>& nodes, std::string& build_err, bool quiet,
+                        const Soa& soa) {
     auto lap = [&](const char* what) {
       if (!timing || quiet) return;
       std::lock_guard<std::mutex> lock(lap_mu);
@@ -1122,24 +1282,13 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     arena[0].count = (uint32_t)order.size();
     arena[0].bounds = bb.range_bounds(0, arena[0].count);
     const uint32_t n = arena[0].count;
-    if (device_builder && !host_only && use_bvh && n >= kDeviceBuildMin) {
+    if (soa.size() == 9 * (size_t)n && n > 0) {
       // the same recursion, level by level on the GPU (bvh_build.hip): identical tree, boxes and order
-      std::vector<float> soa[9];
-      for (auto& v : soa) v.resize(n);
-      parallel_chunks(n, [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-          const HostPrim& p = s.prims[order[i]];
-          soa[0][i] = p.wcentroid.x; soa[1][i] = p.wcentroid.y; soa[2][i] = p.wcentroid.z;
-          soa[3][i] = p.wmin.x; soa[4][i] = p.wmin.y; soa[5][i] = p.wmin.z;
-          soa[6][i] = p.wmax.x; soa[7][i] = p.wmax.y; soa[8][i] = p.wmax.z;
-        }
-      });
-      lap("  host: SoA of centroids/boxes");
       BlasBuildInput in{};
       for (int c = 0; c < 3; ++c) {
-        in.cent[c] = soa[c].data();
-        in.bmin[c] = soa[3 + c].data();
-        in.bmax[c] = soa[6 + c].data();
+        in.cent[c] = soa.data() + (size_t)c * n;
+        in.bmin[c] = soa.data() + (size_t)(3 + c) * n;
+        in.bmax[c] = soa.data() + (size_t)(6 + c) * n;
       }
       in.count = n;
       in.root_min[0] = arena[0].bounds.a.x; in.root_min[1] = arena[0].bounds.a.y; in.root_min[2] = arena[0].bounds.a.z;
@@ -1148,24 +1297,13 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       in.max_depth = 255u;
       in.device = device_ordinal;
       std::vector<uint32_t> perm;
-      std::vector<BlasBuildNode> dn;
-      if (!device_builder(in, perm, dn, build_err)) return false;
+      if (!device_builder(in, perm, arena, build_err)) return false;   // (the arena as the host builder would have made it)
       lap("  gpu build (total)");
       std::vector<uint32_t> permuted(n);
       parallel_chunks(n, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) permuted[i] = order[perm[i]];
       });
       order.swap(permuted);
-      arena.resize(dn.size());
-      parallel_chunks(dn.size(), [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-          arena[i].bounds = Box{point3(dn[i].a[0], dn[i].a[1], dn[i].a[2]), point3(dn[i].b[0], dn[i].b[1], dn[i].b[2])};
-          arena[i].offset = dn[i].offset;
-          arena[i].count = dn[i].count;
-          arena[i].left = dn[i].left;
-          arena[i].right = dn[i].right;
-        }
-      });
     } else if (n > 0) {
       bb.split(arena, 0, 0);
     }
@@ -1176,18 +1314,23 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   };
   for (size_t m = 0; m < blas.size(); ++m) {
     std::string e1, e2;
+    Soa soa;
+    if (device_builder && !host_only && use_bvh && blas[m].prims.size() >= kDeviceBuildMin) {
+      make_soa(blas[m].prims, soa);
+      lap("  host: SoA of centroids/boxes");
+    }
     if (builder == RAYCA_BUILDER_SAH) {
       // two independent trees over the same primitives -- the reference's (tie order + candidate filter) and the one that
       // is traversed -- built side by side: one's host phases (SoA, order, layout) run under the other's GPU levels
       ref_prims[m] = blas[m].prims;
       bool ok_ref = false;
-      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true); });
-      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false);
+      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true, soa); });
+      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false, soa);
       ref_thread.join();
       lap("reference tree + SAH tree");
       if (!ok_ref || !ok) { err = !ok_ref ? e1 : e2; return RAYCA_ERR_HIP; }
     } else {
-      if (!build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false)) { err = e1; return RAYCA_ERR_HIP; }
+      if (!build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false, soa)) { err = e1; return RAYCA_ERR_HIP; }
     }
   }
   std::vector<uint32_t> blas_order(blas.size());
@@ -1240,100 +1383,34 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       base += (uint32_t)bl.prims.size();
     }
     if (base > kLeafFirstMask) { err = "too many primitives for the packed leaf reference (max 33554431)"; return RAYCA_ERR_UNSUPPORTED; }
-    if (on_order_ready) on_order_ready();
+    if (hooks.on_order_ready) hooks.on_order_ready();
     s.root_min = tn[0].bounds.a;
     s.root_max = tn[0].bounds.b;
     uint32_t need = 0;
     s.root_ref = db.emit_tlas(tn, 0, need);
     s.max_depth = need;
     lap("  binary nodes");
-    s.dev_nodes4.clear();
-    // the 4-wide collapse reads the binary nodes and writes its own array: it runs next to the fp16 encoding of the binary
-    // nodes below and is joined before its own fp16 copy is made
-    std::thread wide_thread([&s] {
-      WideBuilder wb{s};
-      uint32_t need4 = 0;
-      s.root_ref4 = wb.build(s.root_ref, need4);
-      s.max_depth4 = need4;
-    });
-    struct Joiner {
-      std::thread& t;
-      ~Joiner() { if (t.joinable()) t.join(); }
-    } wide_joiner{wide_thread};
     s.tie_rank.clear();
     s.ref_leaf_of.clear();
-    s.dev_nodes_h.clear();
-    s.dev_nodes4_h.clear();
     if (builder == RAYCA_BUILDER_SAH) {
-      // fp16 steering boxes: centre of the scene box, power-of-two scale that maps the half extent to <= 2^14
-      float half_extent = 0.0f;
-      const float lo3[3] = {s.root_min.x, s.root_min.y, s.root_min.z}, hi3[3] = {s.root_max.x, s.root_max.y, s.root_max.z};
-      for (int c = 0; c < 3; ++c) {
-        s.half_center[c] = 0.5f * (lo3[c] + hi3[c]);
-        if (!(s.half_center[c] == s.half_center[c]) || std::fabs(s.half_center[c]) > 1e30f) s.half_center[c] = 0.0f;
-        half_extent = std::max(half_extent, std::max(std::fabs(hi3[c] - s.half_center[c]), std::fabs(lo3[c] - s.half_center[c])));
-      }
-      int k = 0;
-      if (half_extent > 0.0f && half_extent < 1e30f) {
-        (void)std::frexp(half_extent * 1.0009765625f, &k);  // half_extent (+ padding) < 2^k
-        k = 14 - k;
-      }
-      k = std::max(-100, std::min(100, k));
-      s.half_scale = std::ldexp(1.0f, k);
-      auto cv = [&](float x, int axis, bool up) -> uint16_t {
-        // only NaNs are unenterable here; the "nowhere" slots are recognised box by box below.  Finite coordinates beyond
-        // the fp16 range saturate OUTWARD (to_half_directed: max -> +inf, min -> -inf), so the box stays conservative
-        // and the frame cannot depend on the node format chosen, whatever the scene's extent.
-        if (!(x == x)) return 0x7E00u;
-        return to_half_directed(((double)x - (double)s.half_center[axis]) * (double)s.half_scale, up);
-      };
-      s.dev_nodes_h.resize(s.dev_nodes.size());
-      parallel_chunks(s.dev_nodes.size(), [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-          const DevNode& n = s.dev_nodes[i];
-          DevNodeH& h = s.dev_nodes_h[i];
-          // q: l.min xyz, l.max xyz, r.min xyz, r.max xyz
-          for (int j = 0; j < 12; ++j) h.h[j] = cv(n.q[j], j % 3, (j / 3) & 1);
-          // an inverted (empty) box and the zero-size "nowhere" box of an unused slot must stay unenterable after
-          // outward rounding
-          for (int side = 0; side < 2; ++side) {
-            bool nowhere = true;
-            for (int j = 0; j < 6; ++j) nowhere = nowhere && n.q[side * 6 + j] == kNowhere;
-            if (nowhere || !(n.q[side * 6] <= n.q[side * 6 + 3]))
-              for (int j = 0; j < 6; ++j) h.h[side * 6 + j] = 0x7E00u;
-          }
-          h.left = n.left;
-          h.right = n.right;
-        }
-      });
-      lap("  binary nodes, fp16");
-      wide_thread.join();
-      lap("  4-wide nodes (rest)");
-      s.dev_nodes4_h.resize(s.dev_nodes4.size());
-      parallel_chunks(s.dev_nodes4.size(), [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-          const DevNode4& n = s.dev_nodes4[i];
-          DevNode4H& h = s.dev_nodes4_h[i];
-          for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 4; ++c) {
-              bool empty = !(n.lo[0][c] <= n.hi[0][c]);
-              if (n.lo[0][c] == kNowhere && n.hi[0][c] == kNowhere && n.lo[1][c] == kNowhere && n.hi[1][c] == kNowhere && n.lo[2][c] == kNowhere &&
-                  n.hi[2][c] == kNowhere)
-                empty = true;  // unused slot (WideBuilder)
-              h.lo[a][c] = empty ? 0x7E00u : cv(n.lo[a][c], a, false);
-              h.hi[a][c] = empty ? 0x7E00u : cv(n.hi[a][c], a, true);
-            }
-          for (int c = 0; c < 4; ++c) h.child[c] = n.child[c];
-        }
-      });
       s.tie_rank.resize(s.prim_order.size());
       s.ref_leaf_of.resize(s.prim_order.size());
-      for (size_t slot = 0; slot < s.prim_order.size(); ++slot) {
-        s.tie_rank[slot] = ref_rank[s.prim_order[slot]];
-        s.ref_leaf_of[slot] = ref_leaf_flat[s.prim_order[slot]];
-      }
+      parallel_chunks(s.prim_order.size(), [&](size_t b, size_t e) {
+        for (size_t slot = b; slot < e; ++slot) {
+          s.tie_rank[slot] = ref_rank[s.prim_order[slot]];
+          s.ref_leaf_of[slot] = ref_leaf_flat[s.prim_order[slot]];
+        }
+      });
     }
   }
+  s.dev_nodes4.clear();
+  s.dev_nodes_h.clear();
+  s.dev_nodes4_h.clear();
+  s.root_ref4 = 0;
+  s.max_depth4 = 0;
+  // the other three node formats are only ever traversed next to the reference-leaf filter
+  s.other_formats_wanted = builder == RAYCA_BUILDER_SAH && !s.blas.empty();
+  if (hooks.with_formats) finish_node_formats(s);
   lap("device node layouts");
   return RAYCA_OK;
 }

@@ -5,8 +5,10 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -107,8 +109,7 @@ struct HostPrim {
   F4 wcentroid, wmin, wmax;
   F4 center;     // sphere
   float radius;
-  PrimExt ext;
-};
+};   // (its shading record lives in HostScene::ext, same index: that array goes to the device as it is)
 
 // std::vector<T>::resize without the zero fill: the flatten order array is ~0.5 KB per triangle (126 MB for the atrium), its
 // slots are written exactly once by the threads that fill them, and value-initialising it first costs a single-threaded
@@ -126,6 +127,24 @@ struct DefaultInitAllocator : std::allocator<T> {
   }
 };
 
+// The same, on whole pages of its own (4 KiB aligned, size rounded up): for the two arrays the library page-locks in
+// place for their upload (pinned_range.hpp) -- a registration works on pages, and a block from the general heap shares its
+// first and last page with whatever lies next to it, possibly a block another thread is registering at that moment.
+template <class T>
+struct PageAllocator : DefaultInitAllocator<T> {
+  template <class U>
+  struct rebind {
+    using other = PageAllocator<U>;
+  };
+  T* allocate(size_t n) {
+    const size_t bytes = (n * sizeof(T) + 4095) / 4096 * 4096;
+    void* p = std::aligned_alloc(4096, bytes ? bytes : 4096);
+    if (!p) throw std::bad_alloc();
+    return static_cast<T*>(p);
+  }
+  void deallocate(T* p, size_t) noexcept { std::free(p); }
+};
+
 struct HostScene {
   std::vector<Trs> local_trs, world_trs;
   bool has_camera = false;
@@ -137,19 +156,25 @@ struct HostScene {
   std::vector<RaycaImage> images;
   std::vector<uint8_t> image_bytes;
   std::vector<HostPrim, DefaultInitAllocator<HostPrim>> prims;      // flatten order
+  // what the device reads per primitive, flatten order, written in place by the flatten threads and uploaded from here
+  // without another copy (the library releases both once they are on the device): the 256-B shading records, and the
+  // world-space triangles, 9 floats each (a sphere's slot: filled by the library when it numbers the sphere table)
+  std::vector<PrimExt, PageAllocator<PrimExt>> ext;
+  std::vector<float, PageAllocator<float>> tris;
   std::vector<HostBlas> blas;       // in TLAS blas_nodes order (post-build)
   uint32_t triangle_count = 0, sphere_count = 0;
 
   // device layout
-  std::vector<DevNode> dev_nodes;
+  std::vector<DevNode, DefaultInitAllocator<DevNode>> dev_nodes;   // (every node is written whole: no zero fill of 17 MB first)
   uint32_t root_ref = 0;            // packed ref of the root
   F4 root_min, root_max;            // root box (tested before anything else, blas.rs:136-139)
   std::vector<uint32_t> prim_order; // slot -> flatten index
   uint32_t max_depth = 0;           // stack entries a traversal can have pending at once
   // the same tree collapsed to 4-wide nodes (every other level skipped): what the kernels traverse
   std::vector<DevNode4> dev_nodes4;
-  std::vector<DevNodeH> dev_nodes_h;     // fp16 versions (SAH builder), see DevNodeH
-  std::vector<DevNode4H> dev_nodes4_h;
+  std::vector<DevNodeH, DefaultInitAllocator<DevNodeH>> dev_nodes_h;     // fp16 versions (SAH builder), see DevNodeH
+  std::vector<DevNode4H, DefaultInitAllocator<DevNode4H>> dev_nodes4_h;
+  bool other_formats_wanted = false;     // finish_node_formats has something to make for this scene
   float half_center[3] = {0, 0, 0};
   float half_scale = 1.0f;               // a power of two
   uint32_t root_ref4 = 0;
@@ -168,10 +193,17 @@ struct HostScene {
 unsigned host_threads();
 
 // Returns RAYCA_OK or an error code with `err` filled.
-// `on_order_ready` (optional) is called once `out.prims`, `out.world_trs` and `out.prim_order` are final -- before the device
-// node layouts are made -- so that the caller can assemble what only depends on them meanwhile.
-int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err,
-                         const std::function<void()>& on_order_ready = {});
+struct BuildHooks {
+  // called once `out.prims` (flatten order: triangles with world-space vertices, shading records, spheres) and
+  // `out.world_trs` are final -- before any BVH work -- so that the caller can start moving them to the device
+  std::function<void()> on_prims_ready;
+  // called once `out.prim_order` (slot -> flatten index) is final -- before the device node layouts are made
+  std::function<void()> on_order_ready;
+  // false leaves the three node formats other than binary f32 to a later finish_node_formats(out)
+  bool with_formats = true;
+};
+int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err, const BuildHooks& hooks = {});
+void finish_node_formats(HostScene& s);
 
 // Device BLAS builder (bvh_build.hip): the same tree and primitive order as the host builder, built on the GPU.
 // host_scene.cpp does not link HIP; the library registers the function before it builds a scene.
@@ -185,16 +217,11 @@ struct BlasBuildInput {
   uint32_t max_depth;
   uint32_t device;
 };
-struct BlasBuildNode {
-  float a[3], b[3];
-  uint32_t offset, count;  // count == 0: inner
-  int32_t left, right;
-};
-using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
+using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err);
 void set_device_blas_builder(BlasBuildFn fn, uint32_t device);
 int32_t selftest_half_rounding(std::string& err);
 int32_t selftest_device_layouts(std::string& err);
-bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BlasBuildNode>& arena, std::string& err);
+bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err);
 const void* gpu_builder_any_kernel();  // host stub of one kernel of bvh_build.hip (to load that code object ahead of time)
 
 }  // namespace rayca

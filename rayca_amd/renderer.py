@@ -71,6 +71,11 @@ class DeviceScene:
         lib.check(self._lib.rayca_hip_scene_info(self.handle, C.byref(i)))
         return i.as_dict()
 
+    def finish(self) -> None:
+        """Wait for the node formats scene_create left to its own thread (rayca_hip_scene_finish): only needed where the
+        first frames must already be eligible for every format (format calibration tests, benchmarks)."""
+        lib.check(self._lib.rayca_hip_scene_finish(self.handle))
+
     def primitive_order(self) -> np.ndarray:
         n = self.info()["triangle_count"] + self.info()["sphere_count"]
         out = np.zeros(n, np.uint32)

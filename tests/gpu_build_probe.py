@@ -12,4 +12,12 @@ for i in range(n):
     ds = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
     t1 = time.perf_counter()
     print(f"[probe] {wl} scene_create #{i}: wall {1e3 * (t1 - t0):.1f} ms, build_ms {ds.info()['build_ms']:.1f}", file=sys.stderr, flush=True)
+    # the literal drop-in draw(): build, one frame, destroy -- the frame runs on the binary nodes while the other formats are made
+    u8, _, st = ds.render(Config(max_depth=1), 1920, 1080, want_f32=False)
+    t2 = time.perf_counter()
+    ds.finish()
+    t3 = time.perf_counter()
     ds.close()
+    t4 = time.perf_counter()
+    print(f"[probe]   first frame +{1e3 * (t2 - t1):.1f} ms (node_format {st['node_format']}), other formats ready +{1e3 * (t3 - t2):.1f} ms, destroy {1e3 * (t4 - t3):.1f} ms",
+          file=sys.stderr, flush=True)
