@@ -1,6 +1,7 @@
 """scene_create timing breakdown (RAYCA_BUILD_TIMING=1 prints the laps to stderr).  usage: python tests/gpu_build_probe.py [atrium|soup] [n]"""
 import os, sys, time
 os.environ["RAYCA_BUILD_TIMING"] = "1"
+os.environ["RAYCA_RENDER_TIMING"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rayca_amd import Config, DeviceScene, flatten, scenes, abi
