@@ -127,24 +127,6 @@ struct DefaultInitAllocator : std::allocator<T> {
   }
 };
 
-// The same, on whole pages of its own (4 KiB aligned, size rounded up): for the two arrays the library page-locks in
-// place for their upload (pinned_range.hpp) -- a registration works on pages, and a block from the general heap shares its
-// first and last page with whatever lies next to it, possibly a block another thread is registering at that moment.
-template <class T>
-struct PageAllocator : DefaultInitAllocator<T> {
-  template <class U>
-  struct rebind {
-    using other = PageAllocator<U>;
-  };
-  T* allocate(size_t n) {
-    const size_t bytes = (n * sizeof(T) + 4095) / 4096 * 4096;
-    void* p = std::aligned_alloc(4096, bytes ? bytes : 4096);
-    if (!p) throw std::bad_alloc();
-    return static_cast<T*>(p);
-  }
-  void deallocate(T* p, size_t) noexcept { std::free(p); }
-};
-
 struct HostScene {
   std::vector<Trs> local_trs, world_trs;
   bool has_camera = false;
@@ -159,8 +141,8 @@ struct HostScene {
   // what the device reads per primitive, flatten order, written in place by the flatten threads and uploaded from here
   // without another copy (the library releases both once they are on the device): the 256-B shading records, and the
   // world-space triangles, 9 floats each (a sphere's slot: filled by the library when it numbers the sphere table)
-  std::vector<PrimExt, PageAllocator<PrimExt>> ext;
-  std::vector<float, PageAllocator<float>> tris;
+  std::vector<PrimExt, DefaultInitAllocator<PrimExt>> ext;
+  std::vector<float, DefaultInitAllocator<float>> tris;
   std::vector<HostBlas> blas;       // in TLAS blas_nodes order (post-build)
   uint32_t triangle_count = 0, sphere_count = 0;
 
