@@ -70,14 +70,14 @@ def workload_config(name):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # (0.4 ms each: long enough that filling and draining four frames in flight is noise)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="atrium")
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--builder", default="sah", choices=["sah", "reference"],
                     help="sah: SAH tree with empty-seeded candidate boxes (default); reference: the reference's tree, quirks included")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames rendered concurrently (frame contexts + streams); 0 = 2 on one GPU, 4 (the HIP hardware queues) with more")
+                    help="frames rendered concurrently (frame contexts + streams); 0 = 4, the number of HIP hardware queues")
     ap.add_argument("--gather-batch", type=int, default=4,
                     help="N > 1: frames per collective of the SECOND timed run (the first, `value`, always gathers every frame on its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,6 +158,11 @@ def main():
     scene = scenes.WORKLOADS["atrium" if args.workload == "atrium4k" else args.workload]["scene"]()
     desc = flatten(scene)
     builder = abi.BUILDER_SAH if args.builder == "sah" else abi.BUILDER_REFERENCE
+    # the streams of the frames in flight, and the comm stream, made before anything else makes streams: each on a
+    # hardware queue of its own (rayca_amd/streams.py -- two frame streams on one queue cost a rank's eighth 0.12-0.16 ms
+    # per frame instead of 0.073)
+    from rayca_amd.streams import frame_streams
+    all_frame_streams, (comm,) = frame_streams(dev, 8, spare=1)
     ds = DeviceScene(desc, cfg, device=dev_index, builder=builder)
     info = ds.info()
     # the same scene once more (rank 0, N = 1 only): what scene_create costs a process that has built a scene before --
@@ -172,17 +177,17 @@ def main():
     # F frames in flight: frame i renders with frame context i % F on its own stream into its own buffer, so the tail
     # of one frame (a few slow waves) overlaps the head of the next; with N > 1 the gather of a finished frame runs on
     # the comm stream meanwhile.  Every frame is still one complete pass: camera rays -> pixels (-> gather).
-    # measured on one MI355X (tests/gpu_inflight_probe.py): a whole 1080p frame per GPU is best with 2 in flight (0.497 ms
-    # against 0.656 with 1), a rank's half / quarter / eighth of it with 4 (0.262 / 0.146 / 0.094 ms); beyond 4 -- the
-    # number of HIP hardware queues -- it gets worse again
+    # measured on one MI355X with every frame stream on a hardware queue of its own (tests/gpu_inflight_probe.py, ms per frame
+    # for 1 / 2 / 3 / 4 / 8 frames in flight): whole 1080p frame 0.538 / 0.420 / 0.412 / 0.404 / 0.406, a rank's half
+    # 0.334 / 0.256 / 0.228 / 0.220 / 0.220, quarter 0.240 / 0.161 / 0.131 / 0.121 / 0.121, eighth 0.206 / 0.120 / 0.087 /
+    # 0.071 / 0.071 -- four, the number of HIP hardware queues (eight queues, GPU_MAX_HW_QUEUES=8, change nothing)
     wl_generations = int(getattr(cfg, "max_depth", 1)) if int(getattr(cfg, "integrator", 5)) == 5 else 1
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world == 1 else 4)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else 4
     F = max(1, min(F, 8))
     outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
     out = outs[0]
-    streams = [torch.cuda.Stream(dev) for _ in range(F)]   # render kernels, one stream per frame in flight
-    stream = streams[0]
-    comm = torch.cuda.Stream(dev)                           # frame gather (RCCL)
+    streams = all_frame_streams[8 - F:]                     # render kernels, one stream per frame in flight
+    stream = streams[0]                                     # (comm, made with them: the frame gather, RCCL)
     gather_dev = dev if backend == "nccl" else torch.device("cpu")
 
     class GatherLoop:

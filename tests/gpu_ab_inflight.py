@@ -11,7 +11,8 @@ vdir = os.path.join(ROOT, "rayca_amd", "csrc", "variants")
 if wl == "atrium": desc = flatten(scenes.atrium_scene()); W, H = 1920, 1080; cfgs = [("pt1", Config(max_depth=1)), ("flat", Config(integrator=IntegratorStrategy.Flat)), ("pt5", Config())]
 else: desc = flatten(scenes.soup_scene()); W, H = 4096, 4096; cfgs = [("flat", Config(integrator=IntegratorStrategy.Flat))]
 dev = torch.device("cuda", 0)
-streams = [torch.cuda.Stream(dev) for _ in range(F)]
+from rayca_amd.streams import frame_streams
+streams = frame_streams(dev, F, spare=0)[0]   # on different hardware queues (rayca_amd/streams.py)
 outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
 dss = {}
 for n in names:

@@ -10,8 +10,10 @@ cfg = Config(max_depth=1) if (len(sys.argv) < 2 or sys.argv[1] != 'flat') else C
 desc = flatten(scenes.atrium_scene())
 dev = torch.device("cuda", 0)
 NH = 8
+from rayca_amd.streams import frame_streams
+streams = frame_streams(dev, NH, spare=0)[0]   # consecutive streams on consecutive hardware queues (rayca_amd/streams.py)
 ds = DeviceScene(desc, cfg, builder=abi.BUILDER_SAH)   # one scene, NH frame contexts
-streams = [torch.cuda.Stream(dev) for _ in range(NH)]
+ds.finish()
 for parts in (1, 2, 4, 8):
     tile = (0, parts, 8)
     rows = ds.tile_rows(tile, H)

@@ -14,14 +14,30 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 cfg, W, H = Config(max_depth=1), 1920, 1080
-ds = DeviceScene(flatten(scenes.atrium_scene()), cfg, builder=abi.BUILDER_SAH)
+# RAYCA_PROBE_STREAMS=first|last|naive: the frame streams from rayca_amd.streams.frame_streams before the scene is made / after
+# it, or the first torch streams asked for after the scene (how the probe used to do it)
+from rayca_amd.streams import frame_streams
+MODE = os.environ.get("RAYCA_PROBE_STREAMS", "first")
+early_streams = None
+if MODE == "first":
+    fs, sp = frame_streams(dev, 8)
+    early_streams = fs + sp
+_lib = None
+if os.environ.get("RAYCA_PROBE_LIB"):   # a library variant from rayca_amd/csrc/variants (tests/build_variants.sh)
+    import ctypes
+    _lib = abi.bind_product_signatures(ctypes.CDLL(os.path.join(ROOT, "rayca_amd", "csrc", "variants", f"librayca_{os.environ['RAYCA_PROBE_LIB']}.so")))
+ds = DeviceScene(flatten(scenes.atrium_scene()), cfg, builder=abi.BUILDER_SAH, **({"_lib": _lib} if _lib else {}))
+ds.finish()
+if MODE == "last":
+    fs, sp = frame_streams(dev, 8)
+    early_streams = fs + sp
 parts_list = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 for parts in parts_list:
     tile = (0, parts, 8)
     rows = ds.tile_rows(tile, H)
     for F in [int(x) for x in os.environ.get("RAYCA_PROBE_F", "2,4").split(",")]:
-        streams = [torch.cuda.Stream(dev) for _ in range(F)]
-        comm = torch.cuda.Stream(dev)
+        streams = early_streams[8 - F:8] if early_streams else [torch.cuda.Stream(dev) for _ in range(F)]
+        comm = early_streams[8] if early_streams else torch.cuda.Stream(dev)
         sends = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
         recv = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev)]
         ev = [torch.cuda.Event() for _ in range(F)]
