@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "host_scene.hpp"
+#include "staging.hpp"
 
 namespace rayca {
 namespace {
@@ -553,8 +554,135 @@ __global__ __launch_bounds__(64) void k_build_small(BuildState st, uint32_t n_sm
 
 const void* gpu_builder_any_kernel() { return reinterpret_cast<const void*>(k_build_small); }
 
+// ---- binary-node layout on the device (what DevBuilder::emit_blas_flat does on the host) ----------------------------------
+// The layout numbers the nodes in pre-order -- a node, its left subtree, its right subtree -- and a leaf above 64 primitives
+// becomes a chain of nodes.  Sizes and stack needs go up the tree (the second child to arrive at a parent finishes it), a
+// node's index is the sum over its ancestors of 1 (+ the left sibling's size where the path turns right), and then every
+// node is written on its own.
+struct LayoutState {
+  const DNode* nodes;
+  uint32_t node_count;
+  uint32_t* parent;   // arena index of the parent, RAYCA_NONE for the root
+  uint32_t* size;     // DevNodes of the subtree
+  uint32_t* need;     // pending stack entries of a traversal of the subtree
+  uint32_t* arrived;  // children that have reported to this node
+  uint32_t* index;    // layout index of the node (of the head of its chain), root = 0
+};
+__device__ __forceinline__ uint32_t chain_nodes(uint32_t count) { return count > kLeafMaxPrims ? (count + kLeafMaxPrims - 1u) / kLeafMaxPrims - 1u : 0u; }
+
+__global__ void k_layout_parents(LayoutState ls) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ls.node_count) return;
+  if (i == 0) ls.parent[0] = RAYCA_NONE;
+  ls.arrived[i] = 0u;
+  const DNode nd = ls.nodes[i];
+  if (nd.left >= 0) {
+    ls.parent[nd.left] = i;
+    ls.parent[nd.right] = i;
+  }
+}
+__global__ void k_layout_sizes(LayoutState ls) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ls.node_count) return;
+  const DNode nd = ls.nodes[i];
+  if (nd.left >= 0) return;  // leaves start the climb
+  const uint32_t chain = chain_nodes(nd.count);
+  __hip_atomic_store(&ls.size[i], chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-scope accesses: another CU reads them)
+  __hip_atomic_store(&ls.need[i], chain ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence();
+  uint32_t p = ls.parent[i];
+  while (p != RAYCA_NONE) {
+    if (atomicAdd(&ls.arrived[p], 1u) == 0u) return;  // the sibling subtree is not finished: its last thread goes on
+    __threadfence();
+    const DNode pn = ls.nodes[p];
+    const uint32_t sl = __hip_atomic_load(&ls.size[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sr = __hip_atomic_load(&ls.size[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nl = __hip_atomic_load(&ls.need[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nr = __hip_atomic_load(&ls.need[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ls.size[p], 1u + sl + sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ls.need[p], 1u + (nl > nr ? nl : nr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    p = ls.parent[p];
+  }
+}
+__global__ void k_layout_index(LayoutState ls) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ls.node_count) return;
+  uint32_t idx = 0, c = i;
+  for (uint32_t p = ls.parent[c]; p != RAYCA_NONE; p = ls.parent[c]) {
+    const DNode pn = ls.nodes[p];
+    idx += 1u + ((uint32_t)pn.right == c ? ls.size[pn.left] : 0u);
+    c = p;
+  }
+  ls.index[i] = idx;
+}
+
+// DevBuilder::put_box (host_scene.cpp), same operations in the same order
+__device__ __forceinline__ void layout_box(float* q, const DNode& nd, float pad_rel, float pad_abs) {
+  float lo[3] = {nd.a[0], nd.a[1], nd.a[2]}, hi[3] = {nd.b[0], nd.b[1], nd.b[2]};
+  if (!(nd.a[0] <= nd.b[0])) {
+    for (int k = 0; k < 3; ++k) lo[k] = hi[k] = kNowhere;
+  } else if (pad_rel > 0.0f) {
+    for (int k = 0; k < 3; ++k) {
+      const float m = fmaxf(fmaxf(fabsf(nd.a[k]), fabsf(nd.b[k])), nd.b[k] - nd.a[k]);
+      const float pad = m * pad_rel + pad_abs;
+      lo[k] = nd.a[k] - pad;
+      hi[k] = nd.b[k] + pad;
+    }
+  }
+  q[0] = lo[0]; q[1] = lo[1]; q[2] = lo[2]; q[3] = hi[0]; q[4] = hi[1]; q[5] = hi[2];
+}
+__device__ __forceinline__ uint32_t layout_leaf_ref(uint32_t first, uint32_t count) { return kLeafFlag | ((count - 1u) << 25) | first; }
+__global__ void k_layout_emit(LayoutState ls, DevNode* out, uint32_t first, uint32_t prim_base, float pad_rel, float pad_abs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ls.node_count) return;
+  const DNode nd = ls.nodes[i];
+  if (nd.left >= 0) {
+    DevNode d;
+    const DNode l = ls.nodes[nd.left], r = ls.nodes[nd.right];
+    layout_box(d.q, l, pad_rel, pad_abs);
+    layout_box(d.q + 6, r, pad_rel, pad_abs);
+    const DNode* kids[2] = {&l, &r};
+    uint32_t refs[2];
+    for (int c = 0; c < 2; ++c) {
+      const DNode& k = *kids[c];
+      const uint32_t ki = (uint32_t)(c ? nd.right : nd.left);
+      if (k.left >= 0) refs[c] = first + ls.index[ki];
+      else if (k.count == 0u) refs[c] = kNoChild;
+      else refs[c] = k.count <= kLeafMaxPrims ? layout_leaf_ref(prim_base + k.offset, k.count) : first + ls.index[ki];
+    }
+    d.left = refs[0]; d.right = refs[1]; d.pad0 = d.pad1 = 0u;
+    out[first + ls.index[i]] = d;
+  } else if (nd.count > kLeafMaxPrims) {  // the chain of DevBuilder::emit_leaf
+    DevNode d;
+    layout_box(d.q, nd, pad_rel, pad_abs);
+    layout_box(d.q + 6, nd, pad_rel, pad_abs);
+    d.pad0 = d.pad1 = 0u;
+    uint32_t cur = first + ls.index[i], f = prim_base + nd.offset, count = nd.count;
+    for (;;) {
+      d.left = layout_leaf_ref(f, kLeafMaxPrims);
+      f += kLeafMaxPrims;
+      count -= kLeafMaxPrims;
+      if (count <= kLeafMaxPrims) {
+        d.right = layout_leaf_ref(f, count);
+        out[cur] = d;
+        break;
+      }
+      d.right = cur + 1u;
+      out[cur] = d;
+      ++cur;
+    }
+  }
+}
+
+// a finished tree that stays on the device until its layout has been written (BlasDeviceTree::handle)
+struct KeptTree {
+  void* pool = nullptr;
+  hipStream_t stream = nullptr;
+  int device = 0;
+  LayoutState ls{};
+};
+
 // BlasBuildFn: see host_scene.hpp
-bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err) {
+bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err, BlasDeviceTree* keep) {
   const uint32_t n = in.count;
   // One device allocation, carved up here, and a stream of its own: a RAYCA_BUILDER_SAH scene builds two trees at the same
   // time from two host threads (host_scene.cpp), and each build is a chain of small launches with a counter read-back per
@@ -594,13 +722,17 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   for (int i = 0; i < 9; ++i) off_u[i] = reserve(sizeof(uint32_t) * ((size_t)n + 2));
   const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_big = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
   const size_t off_chunks[2] = {reserve((size_t)max_chunks * sizeof(uint2)), reserve((size_t)max_chunks * sizeof(uint2))};
+  size_t off_layout[5] = {};
+  if (keep)
+    for (size_t& o : off_layout) o = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2));
   HB_TRY(hipMalloc(&pool, pool_bytes));
   char* base = static_cast<char*>(pool);
   BuildState st{};
   float* f[9];
   for (int i = 0; i < 9; ++i) f[i] = reinterpret_cast<float*>(base + off_f[i]);
   const float* src[9] = {in.cent[0], in.cent[1], in.cent[2], in.bmin[0], in.bmin[1], in.bmin[2], in.bmax[0], in.bmax[1], in.bmax[2]};
-  for (int i = 0; i < 9; ++i) HB_TRY(hipMemcpyAsync(f[i], src[i], sizeof(float) * n, hipMemcpyHostToDevice, stream));
+  StagedCopier staged;   // (page-locked staging blocks: staging.hpp)
+  for (int i = 0; i < 9; ++i) HB_TRY(staged.copy(f[i], src[i], sizeof(float) * n, stream));
   for (int c = 0; c < 3; ++c) {
     st.cent[c] = f[c];
     st.bmin[c] = f[3 + c];
@@ -626,7 +758,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
 
   std::vector<uint32_t> ident(n);
   for (uint32_t i = 0; i < n; ++i) ident[i] = i;
-  HB_TRY(hipMemcpyAsync(st.order, ident.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, stream));
+  HB_TRY(staged.copy(st.order, ident.data(), sizeof(uint32_t) * n, stream));
   DNode root{};
   for (int c = 0; c < 3; ++c) {
     root.a[c] = in.root_min[c];
@@ -642,6 +774,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   const uint32_t zero = 0;
   HB_TRY(hipMemcpyAsync(lists[0], &zero, 4, hipMemcpyHostToDevice, stream));  // level 0: the root
   HB_TRY(hipStreamSynchronize(stream));  // (the sources above are locals and caller memory: staged before they go away)
+  staged.finish();
 
   lap("alloc + upload");
   uint32_t n_active = n > 0 ? 1u : 0u;
@@ -698,6 +831,36 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   uint32_t node_count = 0;
   HB_TRY(hipMemcpyAsync(&node_count, st.node_count, 4, hipMemcpyDeviceToHost, stream));
   HB_TRY(hipStreamSynchronize(stream));
+  if (keep) {  // the tree stays here: work out the layout's size and stack need, hand the pool over
+    LayoutState ls{};
+    ls.nodes = st.nodes;
+    ls.node_count = node_count;
+    uint32_t** parts[5] = {&ls.parent, &ls.size, &ls.need, &ls.arrived, &ls.index};
+    for (int i = 0; i < 5; ++i) *parts[i] = reinterpret_cast<uint32_t*>(base + off_layout[i]);
+    const dim3 grid((node_count + kB - 1) / kB), block(kB);
+    hipLaunchKernelGGL(k_layout_parents, grid, block, 0, stream, ls);
+    hipLaunchKernelGGL(k_layout_sizes, grid, block, 0, stream, ls);
+    hipLaunchKernelGGL(k_layout_index, grid, block, 0, stream, ls);
+    HB_TRY(hipGetLastError());
+    uint32_t root_size = 0, root_need = 0;
+    HB_TRY(hipMemcpyAsync(&root_size, ls.size, 4, hipMemcpyDeviceToHost, stream));
+    HB_TRY(hipMemcpyAsync(&root_need, ls.need, 4, hipMemcpyDeviceToHost, stream));
+    order.resize(n);
+    HB_TRY(hipMemcpyAsync(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream));
+    HB_TRY(hipStreamSynchronize(stream));
+    lap("layout sizes + order");
+    KeptTree* kt = new KeptTree();
+    kt->pool = pool;
+    kt->stream = stream;
+    kt->device = (int)in.device;
+    kt->ls = ls;
+    pool = nullptr;     // (cleanup() below must not release what the handle now owns)
+    stream = nullptr;
+    keep->handle = kt;
+    keep->node_count = root_size;
+    keep->need = root_need;
+    return true;
+  }
   arena.resize(node_count);   // DNode == BuildNode (asserted above): no conversion pass
   order.resize(n);
   HB_TRY(hipMemcpyAsync(static_cast<void*>(arena.data()), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost, stream));
@@ -707,6 +870,34 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   cleanup();
   lap("free");
   return true;
+}
+
+void gpu_release_tree(void* tree) {
+  KeptTree* kt = static_cast<KeptTree*>(tree);
+  if (!kt) return;
+  (void)hipSetDevice(kt->device);
+  if (kt->stream) {
+    (void)hipStreamSynchronize(kt->stream);
+    (void)hipStreamDestroy(kt->stream);
+  }
+  if (kt->pool) (void)hipFree(kt->pool);
+  delete kt;
+}
+
+// Writes the tree's binary nodes into device_nodes[first, first + node_count) -- child indices absolute, leaf references
+// from prim_base on, boxes padded like DevBuilder::put_box pads them -- and releases the tree.
+bool gpu_emit_tree(void* tree, DevNode* device_nodes, uint32_t first, uint32_t prim_base, float pad_rel, float pad_abs, std::string& err) {
+  KeptTree* kt = static_cast<KeptTree*>(tree);
+  if (!kt) { err = "gpu bvh layout: no tree"; return false; }
+  hipError_t e = hipSetDevice(kt->device);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_layout_emit, dim3((kt->ls.node_count + kB - 1) / kB), dim3(kB), 0, kt->stream, kt->ls, device_nodes, first, prim_base, pad_rel, pad_abs);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(kt->stream);
+  if (e != hipSuccess) err = std::string("gpu bvh layout: ") + hipGetErrorString(e);
+  gpu_release_tree(kt);
+  return e == hipSuccess;
 }
 
 }  // namespace rayca

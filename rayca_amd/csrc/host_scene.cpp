@@ -382,8 +382,6 @@ inline uint16_t to_half_directed(double v, bool up) {
 }
 
 // ---- device layout -------------------------------------------------------------------------------
-// Box of a slot that must never be entered (see WideBuilder): a zero-size box far away.
-constexpr float kNowhere = 1.0e18f;
 
 struct DevBuilder {
   HostScene& s;
@@ -533,6 +531,13 @@ struct DevBuilder {
     return true;
   }
   uint32_t emit_blas_node(const HostBlas& bl, uint32_t base, uint32_t idx, uint32_t& need) {
+    if (idx == 0 && bl.dev_tree) {  // built and kept on the device: a run of node indices is set aside, the device fills it
+      const uint32_t first = (uint32_t)s.dev_nodes.size();
+      s.dev_nodes.resize((size_t)first + bl.dev_node_count);
+      s.dev_segments.push_back(DeviceSegment{first, bl.dev_node_count, base, bl.dev_tree});
+      need = bl.dev_need;
+      return first;   // (more than 64 primitives: the root is an inner node or the head of a chain, node 0 of the run)
+    }
     if (idx == 0) {
       uint32_t ref = 0;
       if (emit_blas_flat(bl, base, ref, need)) return ref;
@@ -1251,6 +1256,11 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   const BlasBuildFn device_builder = g_device_builder;
   const uint32_t device_ordinal = g_device_ordinal;
   std::mutex lap_mu;
+  // the traversed tree of a device-built BLAS stays on the device and is laid out there (HostBlas::dev_tree) -- unless the
+  // other node formats are to be made right here, on the host, from the host's copy of the binary nodes
+  const bool keep_trees = !hooks.with_formats;
+  s.dev_segments.clear();
+  s.dev_trees.clear();
   // what the device builder reads: world centroids and boxes of a BLAS's primitives, SoA, in the BLAS's initial order (the
   // two trees of a RAYCA_BUILDER_SAH scene start from the same order and share one copy)
   using Soa = std::vector<float, DefaultInitAllocator<float>>;   // nine planes of n floats, one block
@@ -1268,7 +1278,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     });
   };
   auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<BuildNode>& nodes, std::string& build_err, bool quiet,
-                        const Soa& soa) {
+                        const Soa& soa, BlasDeviceTree* keep) {
     auto lap = [&](const char* what) {
       if (!timing || quiet) return;
       std::lock_guard<std::mutex> lock(lap_mu);
@@ -1297,7 +1307,9 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       in.max_depth = 255u;
       in.device = device_ordinal;
       std::vector<uint32_t> perm;
-      if (!device_builder(in, perm, arena, build_err)) return false;   // (the arena as the host builder would have made it)
+      // (the arena as the host builder would have made it -- or, with `keep`, the tree left on the device and only its
+      // root here)
+      if (!device_builder(in, perm, arena, build_err, keep)) return false;
       lap("  gpu build (total)");
       std::vector<uint32_t> permuted(n);
       parallel_chunks(n, [&](size_t b, size_t e) {
@@ -1324,13 +1336,28 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       // is traversed -- built side by side: one's host phases (SoA, order, layout) run under the other's GPU levels
       ref_prims[m] = blas[m].prims;
       bool ok_ref = false;
-      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true, soa); });
-      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false, soa);
+      BlasDeviceTree kept;
+      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true, soa, nullptr); });
+      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false, soa, keep_trees ? &kept : nullptr);
+      if (kept.handle) {
+        s.dev_trees.push_back(kept.handle);
+        blas[m].dev_tree = kept.handle;
+        blas[m].dev_node_count = kept.node_count;
+        blas[m].dev_need = kept.need;
+      }
       ref_thread.join();
       lap("reference tree + SAH tree");
       if (!ok_ref || !ok) { err = !ok_ref ? e1 : e2; return RAYCA_ERR_HIP; }
     } else {
-      if (!build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false, soa)) { err = e1; return RAYCA_ERR_HIP; }
+      BlasDeviceTree kept;
+      const bool ok = build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false, soa, keep_trees ? &kept : nullptr);
+      if (kept.handle) {
+        s.dev_trees.push_back(kept.handle);
+        blas[m].dev_tree = kept.handle;
+        blas[m].dev_node_count = kept.node_count;
+        blas[m].dev_need = kept.need;
+      }
+      if (!ok) { err = e1; return RAYCA_ERR_HIP; }
     }
   }
   std::vector<uint32_t> blas_order(blas.size());
@@ -1376,6 +1403,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       db.pad_rel = 1.52587890625e-05f;
       db.pad_abs = (diag == diag && diag < FLT_MAX) ? diag * 9.5367431640625e-07f : 0.0f;
     }
+    s.pad_rel = db.pad_rel;
+    s.pad_abs = db.pad_abs;
     uint32_t base = 0;
     for (const HostBlas& bl : s.blas) {
       db.blas_base.push_back(base);

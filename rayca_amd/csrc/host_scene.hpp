@@ -82,6 +82,8 @@ struct DevNode4H {
   uint32_t child[4];
 };
 static_assert(sizeof(DevNode4H) == 64, "DevNode4H is 64 B");
+// Box of a slot that must never be entered (an empty BLAS, an unused slot of a 4-wide node): a zero-size box far away.
+constexpr float kNowhere = 1.0e18f;
 constexpr uint32_t kNoChild = 0x7FFFFFFFu;
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr uint32_t kLeafMaxPrims = 64;
@@ -99,6 +101,16 @@ struct HostBlas {
   uint32_t model = 0;
   std::vector<BuildNode> nodes;     // arena, root at 0
   std::vector<uint32_t> prims;      // indices into HostScene::prims (post-build order)
+  // A BLAS built by the device builder stays on the device (BlasDeviceTree): `nodes` then holds the root only, and the
+  // device lays its nodes out straight into the scene's node array (DeviceSegment, gpu_emit_tree).
+  void* dev_tree = nullptr;
+  uint32_t dev_node_count = 0, dev_need = 0;
+};
+// A run of the scene's binary node array that the device writes itself, from a tree it still holds.
+struct DeviceSegment {
+  uint32_t first = 0, count = 0;    // DevNode indices [first, first + count)
+  uint32_t prim_base = 0;           // first global primitive slot of the BLAS
+  void* tree = nullptr;
 };
 
 struct HostPrim {
@@ -148,6 +160,11 @@ struct HostScene {
 
   // device layout
   std::vector<DevNode, DefaultInitAllocator<DevNode>> dev_nodes;   // (every node is written whole: no zero fill of 17 MB first)
+  // runs of dev_nodes that are NOT filled in here but written on the device (the library emits them into the uploaded
+  // array and copies them back when the host needs them: finish_node_formats), and the box padding they are written with
+  std::vector<DeviceSegment> dev_segments;
+  std::vector<void*> dev_trees;     // every device tree handed out during the build, for the owner to release
+  float pad_rel = 0.0f, pad_abs = 0.0f;
   uint32_t root_ref = 0;            // packed ref of the root
   F4 root_min, root_max;            // root box (tested before anything else, blas.rs:136-139)
   std::vector<uint32_t> prim_order; // slot -> flatten index
@@ -199,11 +216,21 @@ struct BlasBuildInput {
   uint32_t max_depth;
   uint32_t device;
 };
-using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err);
+// `keep` non-null: the finished tree is not copied to the host (arena is left alone) but kept on the device, with the size of
+// its binary-node layout (pre-order, as DevBuilder::emit_blas_flat numbers it) and its stack need already worked out;
+// gpu_emit_tree writes that layout into a device node array and releases the tree, gpu_release_tree only releases it.
+struct BlasDeviceTree {
+  void* handle = nullptr;
+  uint32_t node_count = 0;   // DevNodes the layout takes (inner nodes + the chains of leaves above 64 primitives)
+  uint32_t need = 0;         // stack entries a traversal of it can have pending
+};
+using BlasBuildFn = bool (*)(const BlasBuildInput&, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err, BlasDeviceTree* keep);
 void set_device_blas_builder(BlasBuildFn fn, uint32_t device);
 int32_t selftest_half_rounding(std::string& err);
 int32_t selftest_device_layouts(std::string& err);
-bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err);
+bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std::vector<BuildNode>& arena, std::string& err, BlasDeviceTree* keep);
+bool gpu_emit_tree(void* tree, DevNode* device_nodes, uint32_t first, uint32_t prim_base, float pad_rel, float pad_abs, std::string& err);
+void gpu_release_tree(void* tree);
 const void* gpu_builder_any_kernel();  // host stub of one kernel of bvh_build.hip (to load that code object ahead of time)
 
 }  // namespace rayca
