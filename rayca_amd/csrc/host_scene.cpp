@@ -904,8 +904,10 @@ void set_device_blas_builder(BlasBuildFn fn, uint32_t device) {
 // The three node formats next to the binary f32 one (RAYCA_BUILDER_SAH scenes): the same tree collapsed to 4-wide nodes, and
 // both with fp16 steering boxes.  Reads `s.dev_nodes`, writes `dev_nodes4`, `dev_nodes_h`, `dev_nodes4_h` and their scalars; the
 // library runs it on a thread of its own while the first frames are already traversing the binary nodes.
-void finish_node_formats(HostScene& s) {
+void finish_node_formats(HostScene& s, const std::atomic<bool>* cancel) {
   if (!s.other_formats_wanted) return;
+  auto cancelled = [cancel] { return cancel && cancel->load(std::memory_order_relaxed); };
+  if (cancelled()) return;
   static const bool timing = getenv("RAYCA_BUILD_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -970,6 +972,7 @@ void finish_node_formats(HostScene& s) {
   lap("  binary nodes, fp16");
   wide_thread.join();
   lap("  4-wide nodes (rest)");
+  if (cancelled()) return;
   s.dev_nodes4_h.resize(s.dev_nodes4.size());
   parallel_chunks(s.dev_nodes4.size(), [&](size_t b, size_t e) {
     for (size_t i = b; i < e; ++i) {

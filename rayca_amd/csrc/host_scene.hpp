@@ -3,6 +3,7 @@
 // then conversion of the two-level BVH into the device layout.
 #pragma once
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -202,7 +203,8 @@ struct BuildHooks {
   bool with_formats = true;
 };
 int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err, const BuildHooks& hooks = {});
-void finish_node_formats(HostScene& s);
+// (`cancel`, optional: looked at between the phases; when it reads true the function returns early and the formats are incomplete)
+void finish_node_formats(HostScene& s, const std::atomic<bool>* cancel = nullptr);
 
 // Device BLAS builder (bvh_build.hip): the same tree and primitive order as the host builder, built on the GPU.
 // host_scene.cpp does not link HIP; the library registers the function before it builds a scene.
