@@ -386,6 +386,14 @@ def main():
         rl["achieved"], rl["peak"], rl["unit"], rl["frac"] = top["achieved"], top["peak"], top["unit"], top["frac"]
         rl["traffic"] = lim["hbm_traffic_bytes"]
         rl["hbm_frac"] = lim["limits"]["hbm_traffic"]["frac"]
+        # the same limits over the TIMED REGION: with frames in flight the launches overlap, a frame completes every
+        # ms_per_step, and the chip issues launches_per_frame x the per-launch counters in that time -- the fraction of the
+        # limit the bench's operating point runs at, next to `frac` (one launch alone on the chip, with its tail)
+        step_s = elapsed_max / args.steps
+        if launches_per_frame == 1 and step_s > 0:
+            rl["over_timed_region"] = {k: round(v["frac"] * (trace_ms * 1e-3) / step_s, 4) for k, v in lim["limits"].items()}
+            rl["over_timed_region"]["note"] = f"per-launch counters / ms_per_step ({F} frames in flight): what the chip sustains while frames overlap"
+
     else:   # no counter file for this workload / builder / rank count: the compulsory-bytes HBM figure is what can be stated
         a = compulsory / (trace_ms * 1e-3) / 1e9
         rl["achieved"], rl["peak"], rl["frac"] = round(a, 1), HBM_PEAK_GBS, round(a / HBM_PEAK_GBS, 4)

@@ -677,6 +677,7 @@ __global__ void k_layout_emit(LayoutState ls, DevNode* out, uint32_t first, uint
 struct KeptTree {
   void* pool = nullptr;
   hipStream_t stream = nullptr;
+  bool own_stream = true;
   int device = 0;
   LayoutState ls{};
 };
@@ -689,11 +690,12 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   // level -- on the null stream the two chains would queue behind each other, and two dozen hipMalloc / hipFree pairs cost
   // more than some of the levels.
   void* pool = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = static_cast<hipStream_t>(in.stream);
+  const bool own_stream = stream == nullptr;   // (a caller's stream is only drained here, never destroyed)
   auto cleanup = [&] {
     if (stream) {
       (void)hipStreamSynchronize(stream);
-      (void)hipStreamDestroy(stream);
+      if (own_stream) (void)hipStreamDestroy(stream);
       stream = nullptr;
     }
     if (pool) (void)hipFree(pool);
@@ -709,7 +711,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     tp = now;
   };
   HB_TRY(hipSetDevice((int)in.device));
-  HB_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  if (own_stream) HB_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   const uint32_t max_slots = n / kBig + 2, max_chunks = n / kChunk + max_slots + 2;
   size_t pool_bytes = 0;
   auto reserve = [&](size_t bytes) {  // offsets first, pointers once the pool exists; 256-B aligned pieces
@@ -852,6 +854,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     KeptTree* kt = new KeptTree();
     kt->pool = pool;
     kt->stream = stream;
+    kt->own_stream = own_stream;
     kt->device = (int)in.device;
     kt->ls = ls;
     pool = nullptr;     // (cleanup() below must not release what the handle now owns)
@@ -878,7 +881,7 @@ void gpu_release_tree(void* tree) {
   (void)hipSetDevice(kt->device);
   if (kt->stream) {
     (void)hipStreamSynchronize(kt->stream);
-    (void)hipStreamDestroy(kt->stream);
+    if (kt->own_stream) (void)hipStreamDestroy(kt->stream);
   }
   if (kt->pool) (void)hipFree(kt->pool);
   delete kt;

@@ -1262,6 +1262,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   // the traversed tree of a device-built BLAS stays on the device and is laid out there (HostBlas::dev_tree) -- unless the
   // other node formats are to be made right here, on the host, from the host's copy of the binary nodes
   const bool keep_trees = !hooks.with_formats;
+  void* const bstream[2] = {hooks.build_streams ? hooks.build_streams[0] : nullptr, hooks.build_streams ? hooks.build_streams[1] : nullptr};
   s.dev_segments.clear();
   s.dev_trees.clear();
   // what the device builder reads: world centroids and boxes of a BLAS's primitives, SoA, in the BLAS's initial order (the
@@ -1281,7 +1282,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     });
   };
   auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<BuildNode>& nodes, std::string& build_err, bool quiet,
-                        const Soa& soa, BlasDeviceTree* keep) {
+                        const Soa& soa, BlasDeviceTree* keep, void* stream) {
     auto lap = [&](const char* what) {
       if (!timing || quiet) return;
       std::lock_guard<std::mutex> lock(lap_mu);
@@ -1309,6 +1310,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       in.seed_origin = seed_origin;
       in.max_depth = 255u;
       in.device = device_ordinal;
+      in.stream = stream;
       std::vector<uint32_t> perm;
       // (the arena as the host builder would have made it -- or, with `keep`, the tree left on the device and only its
       // root here)
@@ -1340,8 +1342,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       ref_prims[m] = blas[m].prims;
       bool ok_ref = false;
       BlasDeviceTree kept;
-      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true, soa, nullptr); });
-      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false, soa, keep_trees ? &kept : nullptr);
+      std::thread ref_thread([&] { ok_ref = build_blas(m, true, ref_prims[m], ref_nodes[m], e1, true, soa, nullptr, bstream[0]); });
+      const bool ok = build_blas(m, false, blas[m].prims, blas[m].nodes, e2, false, soa, keep_trees ? &kept : nullptr, bstream[1]);
       if (kept.handle) {
         s.dev_trees.push_back(kept.handle);
         blas[m].dev_tree = kept.handle;
@@ -1353,7 +1355,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       if (!ok_ref || !ok) { err = !ok_ref ? e1 : e2; return RAYCA_ERR_HIP; }
     } else {
       BlasDeviceTree kept;
-      const bool ok = build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false, soa, keep_trees ? &kept : nullptr);
+      const bool ok = build_blas(m, true, blas[m].prims, blas[m].nodes, e1, false, soa, keep_trees ? &kept : nullptr, bstream[1]);
       if (kept.handle) {
         s.dev_trees.push_back(kept.handle);
         blas[m].dev_tree = kept.handle;

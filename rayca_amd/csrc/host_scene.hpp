@@ -201,6 +201,10 @@ struct BuildHooks {
   std::function<void()> on_order_ready;
   // false leaves the three node formats other than binary f32 to a later finish_node_formats(out)
   bool with_formats = true;
+  // two streams (hipStream_t) for the device builder, read after on_prims_ready has returned: the two trees of a
+  // RAYCA_BUILDER_SAH scene are built side by side and only overlap if their streams sit on different hardware queues,
+  // which the owner of the streams can arrange and the builder cannot (api.inc make_scene_streams)
+  void* const* build_streams = nullptr;
 };
 int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder, HostScene& out, std::string& err, const BuildHooks& hooks = {});
 // (`cancel`, optional: looked at between the phases; when it reads true the function returns early and the formats are incomplete)
@@ -217,6 +221,7 @@ struct BlasBuildInput {
   bool seed_origin;       // candidate boxes start at the origin (the reference) or empty (RAYCA_BUILDER_SAH)
   uint32_t max_depth;
   uint32_t device;
+  void* stream = nullptr;  // hipStream_t to build on (the caller keeps it), or null: the builder makes one of its own
 };
 // `keep` non-null: the finished tree is not copied to the host (arena is left alone) but kept on the device, with the size of
 // its binary-node layout (pre-order, as DevBuilder::emit_blas_flat numbers it) and its stack need already worked out;

@@ -33,7 +33,7 @@ class StagingCache {
       }
     }
     void* p = nullptr;
-    if (hipHostMalloc(&p, kStagingBlock, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, kStagingBlock, hipHostMallocPortable) != hipSuccess) {   // (portable: scenes of several devices share the cache)
       (void)hipGetLastError();
       return nullptr;
     }
