@@ -174,6 +174,124 @@ __global__ __launch_bounds__(kBlock, RAYCA_REFILL_WAVES) void k_flat_refill(DevS
   }
 }
 
+
+// ---- queued rays (the wavefront engine's bounce generations) with lane refill ------------------------------------------
+// The same persistent-lane scheme for the rays of an input queue: bounce rays start from scattered points in scattered
+// directions, their searches differ in length far more than camera rays' do, and with one ray per lane for the lifetime of
+// a wave (k_wf_trace) most lanes of a wave sit out most of its trips (measured on the atrium, 4 bounces: 0.47 of the lanes
+// in the node loop, 0.23 in the leaf loop).  Here a lane that has finished its ray writes the hit record and takes the next
+// queue entry.  Items are dealt in batches of 64 consecutive entries through the same per-XCD work counters; closest hits
+// only (4-wide fp16 nodes, RAYCA_WF_BOUNCE_WIDE / _HALF, as k_wf_trace traverses them), every ray still takes its own
+// steps in its own order: the hit records are the ones k_wf_trace writes.
+// Measured (atrium 1080p, default 5-deep Config, four frames in flight, tests/gpu_ab_inflight.py; profiles/r02_ab_qrefill.log):
+// k_wf_trace 4.995 ms per frame, this kernel with (threshold, K) = (44, 32) 4.792, (32, 16) 4.744, (48, 8) 4.736,
+// (24, 8) 4.755, (56, 24) 4.786, (48, 48) 5.29; the 3840x2160 4-bounce frame 19.18 -> 18.18 ms; lanes active in the
+// node loop over the whole frame 0.47 -> 0.56.
+#ifndef RAYCA_QREFILL_THRESHOLD
+#define RAYCA_QREFILL_THRESHOLD 48   // refill when at most this many lanes still hold a live ray
+#endif
+#ifndef RAYCA_QREFILL_LEAVE_K
+#define RAYCA_QREFILL_LEAVE_K 8      // leave the node phase when fewer lanes than this are searching (and a lane holds a leaf)
+#endif
+#ifndef RAYCA_QREFILL_WAVES
+#define RAYCA_QREFILL_WAVES RAYCA_REFILL_WAVES
+#endif
+template <bool SPH, bool STATS>
+__global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_queue_refill(DevScene sc, const QueuedRay* in_rays, const uint32_t* in_count, float4* hits,
+                                                                              uint32_t* heads, TraceCounters* counters, TraceLaunch tl) {
+  constexpr bool WIDE = true, SPILL = true, HALF = true;
+  extern __shared__ uint32_t lds_stack[];
+  NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
+  const uint32_t lane = __lane_id();
+  const uint32_t home = xcc_id();
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  const uint32_t count = *in_count, n_batches = (count + 63u) >> 6;
+  WorkCursor wc;
+  LaneCounters cnt;
+  bool has = false;
+  uint32_t cur = kTerminated, item = 0;
+  DRay ray{};
+  FastRay fr{};
+  DHit hit{};
+  float limit = INFINITY;
+  uint32_t pool_next = 0, pool_end = 0;
+  bool dry = false;
+  for (;;) {
+    const uint32_t n_active = (uint32_t)__popcll(__ballot(cur != kTerminated));
+    if (n_active <= (dry ? 0u : (uint32_t)RAYCA_QREFILL_THRESHOLD)) {
+      if (has && cur == kTerminated) {  // retire: the hit record of this queue entry
+        hits[item] = make_float4(hit.t, __uint_as_float(hit.prim), hit.u, hit.v);
+        has = false;
+      }
+      if (dry && n_active == 0u) break;  // every lane reaches this: n_active and dry are wave-uniform
+      while (!dry) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle == 0ull) break;
+        if (pool_next == pool_end) {
+          const uint32_t batch = next_batch(heads, n_batches, home, wc, tl.ticket);
+          if (batch == RAYCA_NONE) {
+            dry = true;
+            break;
+          }
+          pool_next = batch * 64u;
+          pool_end = min(pool_next + 64u, count);
+        }
+        const uint32_t avail = pool_end - pool_next;
+        const uint32_t rank = (uint32_t)__popcll(idle & lanes_below);
+        if (!has && rank < avail) {
+          item = pool_next + rank;
+          const QueuedRay q = in_rays[item];
+          ray = make_ray(point3(q.ox, q.oy, q.oz), vec3(q.dx, q.dy, q.dz));
+          fr = make_fast(sc, ray, HALF);   // prologue of trace(): the root box first (blas.rs:136-139)
+          hit.t = INFINITY;
+          hit.prim = RAYCA_NONE;
+          hit.u = hit.v = 0.0f;
+          limit = INFINITY;
+          stack.clear();
+          float tmin;
+          if (STATS) cnt.boxes++;
+          cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? sc.root_ref4 : kTerminated;
+          has = true;
+        }
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        pool_next += n_idle < avail ? n_idle : avail;
+      }
+    }
+    for (;;) {  // (RAYCA_REFILL_SCHED 0 of k_flat_refill)
+      const bool searching = !(cur & kLeafFlag) && cur != kTerminated;
+      const uint32_t n = (uint32_t)__popcll(__ballot(searching));
+      if (n == 0u) break;
+      if (n < (uint32_t)RAYCA_QREFILL_LEAVE_K && __ballot((cur & kLeafFlag) != 0u) != 0ull) break;
+      if (searching) cur = node_step<true, true, WIDE, SPILL, STATS, HALF>(sc, ray, fr, limit, cur, stack, cnt);
+    }
+    if (cur & kLeafFlag) {
+      test_leaf<true, SPH, STATS>(sc, ray, cur, FLT_MAX, hit, limit, cnt);
+      cur = stack.pop();
+    }
+  }
+  if (STATS) {
+    unsigned long long b = cnt.boxes, t = cnt.tris, sb = cnt.slot_boxes, stt = cnt.slot_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off);
+      t += __shfl_down(t, off);
+      sb += __shfl_down(sb, off);
+      stt += __shfl_down(stt, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&counters->boxes, b);
+      atomicAdd(&counters->tris, t);
+      atomicAdd(&counters->box_slots, sb);
+      atomicAdd(&counters->tri_slots, stt);
+    }
+  }
+}
+
+using QueueRefillKernel = void (*)(DevScene, const QueuedRay*, const uint32_t*, float4*, uint32_t*, TraceCounters*, TraceLaunch);
+QueueRefillKernel pick_queue(bool sph, bool stats) {
+  if (sph) return stats ? k_queue_refill<true, true> : k_queue_refill<true, false>;
+  return stats ? k_queue_refill<false, true> : k_queue_refill<false, false>;
+}
+
 using RefillKernel = void (*)(DevScene, FrameParams, uint32_t*, uint8_t*, float4*, TraceCounters*, TraceLaunch);
 template <bool SPH, bool STATS>
 RefillKernel pick2(bool wide, bool spill, bool half) {
@@ -193,6 +311,13 @@ const void* flat_refill_kernel(const RefillFlavour& f) { return reinterpret_cast
 void launch_flat_refill(const RefillFlavour& f, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const FrameParams& fp, uint32_t* heads,
                         uint8_t* rgba8, float4* rgba32f, TraceCounters* counters, const TraceLaunch& tl) {
   hipLaunchKernelGGL(pick(f), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, fp, heads, rgba8, rgba32f, counters, tl);
+}
+
+const void* queue_refill_kernel(bool sph, bool stats) { return reinterpret_cast<const void*>(pick_queue(sph, stats)); }
+
+void launch_queue_refill(bool sph, bool stats, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const QueuedRay* in_rays,
+                         const uint32_t* in_count, float4* hits, uint32_t* heads, TraceCounters* counters, const TraceLaunch& tl) {
+  hipLaunchKernelGGL(pick_queue(sph, stats), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, in_rays, in_count, hits, heads, counters, tl);
 }
 
 }  // namespace rayca

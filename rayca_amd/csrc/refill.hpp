@@ -14,4 +14,9 @@ const void* flat_refill_kernel(const RefillFlavour& f);
 void launch_flat_refill(const RefillFlavour& f, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const FrameParams& fp, uint32_t* heads,
                         uint8_t* rgba8, float4* rgba32f, TraceCounters* counters, const TraceLaunch& tl);
 
+// the same for the rays of a queue (closest hits of a bounce generation of the wavefront engine; 4-wide fp16 nodes)
+const void* queue_refill_kernel(bool sph, bool stats);
+void launch_queue_refill(bool sph, bool stats, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const QueuedRay* in_rays,
+                         const uint32_t* in_count, float4* hits, uint32_t* heads, TraceCounters* counters, const TraceLaunch& tl);
+
 }  // namespace rayca
