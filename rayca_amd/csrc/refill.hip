@@ -286,6 +286,153 @@ __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_queue_refill(De
   }
 }
 
+
+// The shadow-ray pass the same way (k_wf_shadow: a lane owns a pixel, traces its shadow rays in sample order and sums the
+// direct light exactly like the NEE loop of k_generation).  A shadow ray ends at the first occluder, so the searches of a
+// wave differ in length even more than closest-hit searches do; and the items that have no lit vertex never occupy a lane.
+// A lane whose ray is done adds its sample, then takes the pixel's next shadow ray or -- after the last -- writes the sum and
+// takes the next item.  Items: the tile list for generation 0, the input queue after; the other set of work counters
+// (heads_b), since the closest-hit pass of the same generation has used the first.
+template <bool GEN0, bool SPH, bool STATS>
+__global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_shadow_refill(DevScene sc, FrameParams fp, const QueuedRay* in_rays, const uint32_t* in_count, WfBuffers wb,
+                                                                                PathBuffers pb, uint32_t depth, uint32_t* heads, TraceCounters* counters, TraceLaunch tl) {
+  constexpr bool WIDE = true, SPILL = true, HALF = true;
+  extern __shared__ uint32_t lds_stack[];
+  NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
+  const uint32_t lane = __lane_id();
+  const uint32_t home = xcc_id();
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  const uint32_t count = GEN0 ? fp.tile_count * 64u : *in_count, n_batches = (count + 63u) >> 6;
+  WorkCursor wc;
+  LaneCounters cnt;
+  bool has = false;          // the lane holds a pixel whose shadow rays are not all done
+  uint32_t cur = kTerminated, p = 0, j = 0, quad = 0;
+  float t_stop = FLT_MAX;
+  Color direct = black();
+  DRay ray{};
+  FastRay fr{};
+  DHit hit{};
+  float limit = INFINITY;
+  uint32_t pool_next = 0, pool_end = 0;
+  bool dry = false;
+  // the j-th shadow ray of pixel p: prologue of trace() with the any-hit bound
+  auto start_ray = [&]() {
+    const size_t e = (size_t)j * pb.npix + p;
+    const float4 a = wb.sh_ray[2 * e], b = wb.sh_ray[2 * e + 1];
+    quad = __float_as_uint(b.w);
+    t_stop = a.w;
+    ray = make_ray(point3(a.x, a.y, a.z), vec3(b.x, b.y, b.z));
+    fr = make_fast(sc, ray, HALF);
+    hit.t = INFINITY;
+    hit.prim = RAYCA_NONE;
+    hit.u = hit.v = 0.0f;
+    limit = t_stop < FLT_MAX ? t_stop + fabsf(t_stop) * 9.765625e-4f + sc.cull_abs : INFINITY;
+    stack.clear();
+    float tmin;
+    if (STATS) cnt.boxes++;
+    cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? sc.root_ref4 : kTerminated;
+  };
+  for (;;) {
+    const uint32_t n_active = (uint32_t)__popcll(__ballot(cur != kTerminated));
+    if (n_active <= (dry ? 0u : (uint32_t)RAYCA_QREFILL_THRESHOLD)) {
+      if (has && cur == kTerminated) {  // retire a shadow ray: k_wf_shadow's statements
+        const bool found = hit.prim != RAYCA_NONE;
+        bool lit;
+        if (quad) {
+          lit = false;
+          if (found) {
+            const uint32_t hm = sc.ext[hit.prim].material;
+            lit = hm != RAYCA_NONE && hm < sc.material_count && sc.materials[hm].emissive != 0u;
+          }
+        } else {
+          lit = !(found && hit.t < t_stop);
+        }
+        const size_t e = (size_t)j * pb.npix + p;
+        direct = direct + (lit ? as_color(wb.sh_x[e]) : black());
+        if (++j == wb.nls) {
+          pb.direct[(size_t)depth * pb.npix + p] = as_f4(direct);
+          has = false;
+        } else {
+          start_ray();
+        }
+      }
+      // (every lane reaches this: both operands are wave-uniform.  A lane that still holds a pixel -- its next ray started by
+      // the retire above, or ended at the root box at once -- keeps the wave going; it retires on a later trip)
+      if (dry && __ballot(has) == 0ull) break;
+      while (!dry) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle == 0ull) break;
+        if (pool_next == pool_end) {
+          const uint32_t batch = next_batch(heads, n_batches, home, wc, tl.ticket);
+          if (batch == RAYCA_NONE) {
+            dry = true;
+            break;
+          }
+          pool_next = batch * 64u;
+          pool_end = min(pool_next + 64u, count);
+        }
+        const uint32_t avail = pool_end - pool_next;
+        const uint32_t rank = (uint32_t)__popcll(idle & lanes_below);
+        if (!has && rank < avail) {
+          const uint32_t item = pool_next + rank;
+          uint32_t px = RAYCA_NONE;
+          if (GEN0) {
+            uint32_t x = 0, r = 0;
+            if (tile_item_pixel(fp, item, x, r)) px = r * fp.width + x;
+          } else {
+            px = in_rays[item].pixel;
+          }
+          if (px != RAYCA_NONE) {  // (items without a lit vertex are skipped: the lane asks again)
+            const uint32_t st = pb.state[(size_t)depth * pb.npix + px];
+            if (st == kVertexLit || st == kVertexLitNoIndirect) {
+              p = px;
+              j = 0;
+              direct = black();
+              has = true;
+              start_ray();
+            }
+          }
+        }
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        pool_next += n_idle < avail ? n_idle : avail;
+      }
+    }
+    for (;;) {
+      const bool searching = !(cur & kLeafFlag) && cur != kTerminated;
+      const uint32_t n = (uint32_t)__popcll(__ballot(searching));
+      if (n == 0u) break;
+      if (n < (uint32_t)RAYCA_QREFILL_LEAVE_K && __ballot((cur & kLeafFlag) != 0u) != 0ull) break;
+      if (searching) cur = node_step<true, true, WIDE, SPILL, STATS, HALF>(sc, ray, fr, limit, cur, stack, cnt);
+    }
+    if (cur & kLeafFlag) {
+      test_leaf<true, SPH, STATS>(sc, ray, cur, t_stop, hit, limit, cnt);
+      cur = (t_stop < FLT_MAX && hit.t < t_stop) ? kTerminated : stack.pop();   // any hit in front of the light ends the search (trace())
+    }
+  }
+  if (STATS) {
+    unsigned long long b = cnt.boxes, t = cnt.tris, sb = cnt.slot_boxes, stt = cnt.slot_tris;
+    for (int off = 32; off > 0; off >>= 1) {
+      b += __shfl_down(b, off);
+      t += __shfl_down(t, off);
+      sb += __shfl_down(sb, off);
+      stt += __shfl_down(stt, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&counters->boxes, b);
+      atomicAdd(&counters->tris, t);
+      atomicAdd(&counters->box_slots, sb);
+      atomicAdd(&counters->tri_slots, stt);
+    }
+  }
+}
+
+using ShadowRefillKernel = void (*)(DevScene, FrameParams, const QueuedRay*, const uint32_t*, WfBuffers, PathBuffers, uint32_t, uint32_t*, TraceCounters*, TraceLaunch);
+template <bool GEN0>
+ShadowRefillKernel pick_shadow(bool sph, bool stats) {
+  if (sph) return stats ? k_shadow_refill<GEN0, true, true> : k_shadow_refill<GEN0, true, false>;
+  return stats ? k_shadow_refill<GEN0, false, true> : k_shadow_refill<GEN0, false, false>;
+}
+
 using QueueRefillKernel = void (*)(DevScene, const QueuedRay*, const uint32_t*, float4*, uint32_t*, TraceCounters*, TraceLaunch);
 QueueRefillKernel pick_queue(bool sph, bool stats) {
   if (sph) return stats ? k_queue_refill<true, true> : k_queue_refill<true, false>;
@@ -318,6 +465,25 @@ const void* queue_refill_kernel(bool sph, bool stats) { return reinterpret_cast<
 void launch_queue_refill(bool sph, bool stats, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const QueuedRay* in_rays,
                          const uint32_t* in_count, float4* hits, uint32_t* heads, TraceCounters* counters, const TraceLaunch& tl) {
   hipLaunchKernelGGL(pick_queue(sph, stats), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, in_rays, in_count, hits, heads, counters, tl);
+}
+
+const void* shadow_refill_kernel(bool gen0, bool sph, bool stats) {
+  return reinterpret_cast<const void*>(gen0 ? pick_shadow<true>(sph, stats) : pick_shadow<false>(sph, stats));
+}
+
+void launch_shadow_refill(bool gen0, bool sph, bool stats, uint32_t grid, size_t lds_bytes, hipStream_t stream, const DevScene& sc, const FrameParams& fp,
+                          const QueuedRay* in_rays, const uint32_t* in_count, const ShadowRefillArgs& a, uint32_t depth, uint32_t* heads,
+                          TraceCounters* counters, const TraceLaunch& tl) {
+  WfBuffers wb{};
+  wb.sh_ray = a.sh_ray;
+  wb.sh_x = a.sh_x;
+  wb.nls = a.nls;
+  PathBuffers pb{};
+  pb.direct = a.direct;
+  pb.state = a.state;
+  pb.npix = a.npix;
+  hipLaunchKernelGGL(gen0 ? pick_shadow<true>(sph, stats) : pick_shadow<false>(sph, stats), dim3(grid), dim3(kBlock), lds_bytes, stream, sc, fp, in_rays, in_count, wb,
+                     pb, depth, heads, counters, tl);
 }
 
 }  // namespace rayca
