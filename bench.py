@@ -165,13 +165,6 @@ def main():
     all_frame_streams, (comm,) = frame_streams(dev, 8, spare=1)
     ds = DeviceScene(desc, cfg, device=dev_index, builder=builder)
     info = ds.info()
-    # the same scene once more (rank 0, N = 1 only): what scene_create costs a process that has built a scene before --
-    # the first one of a process also pays first use of the runtime's copy and page-locking paths
-    build_ms_again = None
-    if rank == 0 and world == 1:
-        again = DeviceScene(desc, cfg, device=dev_index, builder=builder)
-        build_ms_again = round(again.info()["build_ms"], 1)
-        again.close()
     tile = tile_of(rank, world, args.band_rows)
     my_rows = int(rows_of(tile, H).numel())
     # F frames in flight: frame i renders with frame context i % F on its own stream into its own buffer, so the tail
@@ -351,7 +344,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": wl["label"], "width": W, "height": H, "triangles": info["triangle_count"],
-                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "bvh_build_ms_second_scene": build_ms_again, "hip_runtime_init_ms": round(info["runtime_init_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
+                   "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "hip_runtime_init_ms": round(info["runtime_init_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
                    "node_format": {"generation0": ("4-wide" if node_format & 1 else "binary") + (" fp16" if node_format & 4 else " f32"),
                                    "bounces": ("4-wide" if node_format & 2 else "binary") + (" fp16" if node_format & 8 else " f32"),
                                    "camera_rays": "lane-refill kernel (refill.hip)" if node_format & 1024 else "generation kernel",
