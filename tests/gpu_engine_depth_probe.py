@@ -1,4 +1,4 @@
-"""Which engine for how many generations?  Fused and wavefront engines on path frames of depth 1..5, two frames in
+"""Which engine for how many generations?  Fused and wavefront engines on path frames of depth 1..5, four frames in
 flight (the bench's operating point).  usage: python tests/gpu_engine_depth_probe.py [workload]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,10 +7,12 @@ import numpy as np, torch
 from rayca_amd import Config, DeviceScene, flatten, scenes, abi
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 desc = flatten(scenes.atrium_scene() if wl == "atrium" else scenes.cornell_scene())
-W, H, F = 1920, 1080, 2
+W, H, F = 1920, 1080, 4
 dev = torch.device("cuda", 0)
+from rayca_amd.streams import frame_streams
+streams = frame_streams(dev, F, spare=0)[0]   # each on a hardware queue of its own
 ds = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
-streams = [torch.cuda.Stream(dev) for _ in range(F)]
+ds.finish()
 outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
 for depth in (1, 2, 3, 4, 5):
     cfg = Config(max_depth=depth)
