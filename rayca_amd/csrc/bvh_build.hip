@@ -20,6 +20,7 @@
 
 #include <thread>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstddef>
 #include <chrono>
@@ -599,6 +600,13 @@ struct LayoutState {
   uint32_t* need;     // pending stack entries of a traversal of the subtree
   uint32_t* arrived;  // children that have reported to this node
   uint32_t* index;    // layout index of the node (of the head of its chain), root = 0
+  uint32_t* prims;    // primitives below the node
+  float* cost;        // expected cost of traversing the subtree as it is laid out, in triangle tests x box area
+  uint32_t* leafed;   // 1: the subtree is laid out as ONE leaf (its primitives are a contiguous range of the order)
+  // subtrees that are no dearer as one leaf are laid out as one (host_scene.hpp kLeafNodeCost; the same arithmetic as
+  // DevBuilder::plan_leaves on the host); node_cost 0: the tree as built
+  float node_cost;
+  uint32_t leaf_max;
 };
 __device__ __forceinline__ uint32_t chain_nodes(uint32_t count) { return count > kLeafMaxPrims ? (count + kLeafMaxPrims - 1u) / kLeafMaxPrims - 1u : 0u; }
 
@@ -621,6 +629,9 @@ __global__ void k_layout_sizes(LayoutState ls) {
   const uint32_t chain = chain_nodes(nd.count);
   __hip_atomic_store(&ls.size[i], chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-scope accesses: another CU reads them)
   __hip_atomic_store(&ls.need[i], chain ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&ls.prims[i], nd.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&ls.cost[i], (float)nd.count * area3(nd.a, nd.b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ls.leafed[i] = 0u;
   __threadfence();
   uint32_t p = ls.parent[i];
   while (p != RAYCA_NONE) {
@@ -629,8 +640,16 @@ __global__ void k_layout_sizes(LayoutState ls) {
     const DNode pn = ls.nodes[p];
     const uint32_t sl = __hip_atomic_load(&ls.size[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sr = __hip_atomic_load(&ls.size[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t nl = __hip_atomic_load(&ls.need[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nr = __hip_atomic_load(&ls.need[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ls.size[p], 1u + sl + sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ls.need[p], 1u + (nl > nr ? nl : nr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t pl = __hip_atomic_load(&ls.prims[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pr = __hip_atomic_load(&ls.prims[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float cl = __hip_atomic_load(&ls.cost[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cr = __hip_atomic_load(&ls.cost[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float area = area3(pn.a, pn.b), as_leaf = (float)(pl + pr) * area, as_split = ls.node_cost * area + cl + cr;
+    // (the whole subtree becomes one leaf reference in its parent: no nodes of its own)
+    const bool one_leaf = ls.node_cost > 0.0f && pl + pr <= ls.leaf_max && as_leaf <= as_split;
+    ls.leafed[p] = one_leaf ? 1u : 0u;
+    __hip_atomic_store(&ls.cost[p], one_leaf ? as_leaf : as_split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ls.prims[p], pl + pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ls.size[p], one_leaf ? 0u : 1u + sl + sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ls.need[p], one_leaf ? 0u : 1u + (nl > nr ? nl : nr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     p = ls.parent[p];
   }
@@ -639,12 +658,15 @@ __global__ void k_layout_index(LayoutState ls) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ls.node_count) return;
   uint32_t idx = 0, c = i;
+  bool inside = false;   // below a subtree that is laid out as one leaf: this node is not laid out at all
   for (uint32_t p = ls.parent[c]; p != RAYCA_NONE; p = ls.parent[c]) {
     const DNode pn = ls.nodes[p];
     idx += 1u + ((uint32_t)pn.right == c ? ls.size[pn.left] : 0u);
+    inside = inside || ls.leafed[p] != 0u;
     c = p;
   }
   ls.index[i] = idx;
+  if (inside) ls.leafed[i] = 2u;
 }
 
 // DevBuilder::put_box (host_scene.cpp), same operations in the same order
@@ -668,6 +690,7 @@ __global__ void k_layout_emit(LayoutState ls, DevNode* out, uint32_t first, uint
   if (i >= ls.node_count) return;
   const DNode nd = ls.nodes[i];
   if (nd.left >= 0) {
+    if (ls.leafed[i] != 0u) return;   // the root of, or inside, a subtree that is one leaf: the reference sits in a node above
     DevNode d;
     const DNode l = ls.nodes[nd.left], r = ls.nodes[nd.right];
     layout_box(d.q, l, pad_rel, pad_abs);
@@ -677,7 +700,7 @@ __global__ void k_layout_emit(LayoutState ls, DevNode* out, uint32_t first, uint
     for (int c = 0; c < 2; ++c) {
       const DNode& k = *kids[c];
       const uint32_t ki = (uint32_t)(c ? nd.right : nd.left);
-      if (k.left >= 0) refs[c] = first + ls.index[ki];
+      if (k.left >= 0) refs[c] = ls.leafed[ki] == 1u ? layout_leaf_ref(prim_base + k.offset, ls.prims[ki]) : first + ls.index[ki];
       else if (k.count == 0u) refs[c] = kNoChild;
       else refs[c] = k.count <= kLeafMaxPrims ? layout_leaf_ref(prim_base + k.offset, k.count) : first + ls.index[ki];
     }
@@ -756,7 +779,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   for (int i = 0; i < 9; ++i) off_u[i] = reserve(sizeof(uint32_t) * ((size_t)n + 2));
   const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_big = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
   const size_t off_chunks[2] = {reserve((size_t)max_chunks * sizeof(uint2)), reserve((size_t)max_chunks * sizeof(uint2))};
-  size_t off_layout[5] = {};
+  size_t off_layout[8] = {};
   if (keep)
     for (size_t& o : off_layout) o = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2));
   HB_TRY(hipMalloc(&pool, pool_bytes));
@@ -869,8 +892,11 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     LayoutState ls{};
     ls.nodes = st.nodes;
     ls.node_count = node_count;
-    uint32_t** parts[5] = {&ls.parent, &ls.size, &ls.need, &ls.arrived, &ls.index};
-    for (int i = 0; i < 5; ++i) *parts[i] = reinterpret_cast<uint32_t*>(base + off_layout[i]);
+    uint32_t** parts[7] = {&ls.parent, &ls.size, &ls.need, &ls.arrived, &ls.index, &ls.prims, &ls.leafed};
+    for (int i = 0; i < 7; ++i) *parts[i] = reinterpret_cast<uint32_t*>(base + off_layout[i]);
+    ls.cost = reinterpret_cast<float*>(base + off_layout[7]);
+    ls.node_cost = in.layout_node_cost;
+    ls.leaf_max = std::min<uint32_t>(std::max<uint32_t>(in.layout_leaf_max, 1u), kLeafMaxPrims);
     const dim3 grid((node_count + kB - 1) / kB), block(kB);
     hipLaunchKernelGGL(k_layout_parents, grid, block, 0, stream, ls);
     hipLaunchKernelGGL(k_layout_sizes, grid, block, 0, stream, ls);

@@ -387,6 +387,38 @@ struct DevBuilder {
   HostScene& s;
   std::vector<uint32_t> blas_base;  // first global primitive slot of each BLAS (TLAS order)
   float pad_rel = 0.0f, pad_abs = 0.0f;  // RAYCA_BUILDER_SAH: conservative boxes (see build_host_scene)
+  // subtrees laid out as one leaf (host_scene.hpp kLeafNodeCost): the same decisions, by the same arithmetic, as the
+  // device layout makes for a tree it holds (bvh_build.hip k_layout_sizes)
+  float node_cost = 0.0f;
+  uint32_t leaf_max = kLeafCollapseMax;
+  std::vector<uint32_t> plan_prims;   // per arena node of the BLAS being laid out: primitives below it
+  std::vector<uint8_t> plan_leafed;   // 1: the subtree is one leaf, 2: inside such a subtree
+  void plan_leaves(const HostBlas& bl) {
+    const std::vector<BuildNode>& a = bl.nodes;
+    const size_t n = a.size();
+    plan_prims.assign(n, 0u);
+    plan_leafed.assign(n, 0);
+    std::vector<float> cost(n, 0.0f);
+    for (size_t i = n; i-- > 0;) {  // children sit behind their parents
+      const BuildNode& bn = a[i];
+      if (bn.left < 0) {
+        plan_prims[i] = bn.count;
+        cost[i] = (float)bn.count * area(bn.bounds);
+        continue;
+      }
+      const uint32_t pl = plan_prims[bn.left], pr = plan_prims[bn.right];
+      const float ar = area(bn.bounds), as_leaf = (float)(pl + pr) * ar, as_split = node_cost * ar + cost[bn.left] + cost[bn.right];
+      const bool one_leaf = node_cost > 0.0f && pl + pr <= leaf_max && as_leaf <= as_split;
+      plan_leafed[i] = one_leaf ? 1 : 0;
+      cost[i] = one_leaf ? as_leaf : as_split;
+      plan_prims[i] = pl + pr;
+    }
+    for (size_t i = 0; i < n; ++i) {  // everything below a one-leaf subtree is not laid out at all
+      const BuildNode& bn = a[i];
+      if (bn.left < 0 || plan_leafed[i] == 0) continue;
+      plan_leafed[bn.left] = plan_leafed[bn.right] = 2;
+    }
+  }
 
   void put_box(DevNode& n, int side, const Box& b0) {
     Box b = b0;
@@ -476,8 +508,9 @@ struct DevBuilder {
         stack_need[i] = chain ? 1u : 0u;
       } else {
         if ((size_t)bn.left <= i || (size_t)bn.right <= i || (size_t)bn.left >= n || (size_t)bn.right >= n) return false;
-        size[i] = 1u + size[bn.left] + size[bn.right];
-        stack_need[i] = 1u + std::max(stack_need[bn.left], stack_need[bn.right]);
+        const bool one_leaf = plan_leafed[i] != 0;   // (its parent holds a leaf reference, it takes no nodes)
+        size[i] = one_leaf ? 0u : 1u + size[bn.left] + size[bn.right];
+        stack_need[i] = one_leaf ? 0u : 1u + std::max(stack_need[bn.left], stack_need[bn.right]);
       }
     }
     const uint32_t first = (uint32_t)s.dev_nodes.size();
@@ -492,13 +525,14 @@ struct DevBuilder {
     s.dev_nodes.resize((size_t)first + size[0]);
     auto ref_of = [&](size_t i) -> uint32_t {  // what the parent stores for child i
       const BuildNode& bn = a[i];
-      if (bn.left >= 0) return index[i];
+      if (bn.left >= 0) return plan_leafed[i] == 1 ? leaf_ref(base + bn.offset, plan_prims[i]) : index[i];
       if (bn.count == 0) return kNoChild;
       return bn.count <= kLeafMaxPrims ? leaf_ref(base + bn.offset, bn.count) : index[i];
     };
     parallel_chunks(n, [&](size_t b, size_t e) {
       for (size_t i = b; i < e; ++i) {
         const BuildNode& bn = a[i];
+        if (plan_leafed[i] != 0) continue;  // the root of, or inside, a subtree that is one leaf
         if (bn.left >= 0) {
           DevNode& d = s.dev_nodes[index[i]];
           std::memset(&d, 0, sizeof d);
@@ -539,11 +573,16 @@ struct DevBuilder {
       return first;   // (more than 64 primitives: the root is an inner node or the head of a chain, node 0 of the run)
     }
     if (idx == 0) {
+      plan_leaves(bl);
       uint32_t ref = 0;
       if (emit_blas_flat(bl, base, ref, need)) return ref;
     }
     const BuildNode& bn = bl.nodes[idx];
     if (bn.left < 0) return emit_leaf(base + bn.offset, bn.count, bn.bounds, need);
+    if (plan_leafed[idx] == 1) {  // the whole subtree as one leaf
+      need = 0;
+      return leaf_ref(base + bn.offset, plan_prims[idx]);
+    }
     const uint32_t n = new_node();
     put_box(s.dev_nodes[n], 0, bl.nodes[bn.left].bounds);
     put_box(s.dev_nodes[n], 1, bl.nodes[bn.right].bounds);
@@ -816,31 +855,34 @@ int32_t selftest_device_layouts(std::string& err) {
     bl.nodes.push_back(r);
     bl.nodes[i].count = 0;
   }
-  HostScene a, b;
-  uint32_t ref[2], need[2], ref4[2], need4[2];
-  HostScene* scenes[2] = {&a, &b};
-  for (int pass = 0; pass < 2; ++pass) {
-    HostScene& s = *scenes[pass];
-    s.blas.push_back(bl);
-    DevBuilder db{s, {0u}};
-    db.pad_rel = 1.52587890625e-05f;
-    db.pad_abs = 1e-6f;
-    db.allow_flat = pass == 1;
-    ref[pass] = db.emit_blas_node(s.blas[0], 0, 0, need[pass]);
-    WideBuilder wb{s};
-    wb.allow_parallel = pass == 1;
-    ref4[pass] = wb.build(ref[pass], need4[pass]);
-  }
-  if (a.dev_nodes.size() < 65536) { err = "layout self-test: the random tree came out too small to exercise the parallel passes"; return RAYCA_ERR_BAD_ARG; }
-  if (ref[0] != ref[1] || need[0] != need[1] || a.dev_nodes.size() != b.dev_nodes.size() ||
-      std::memcmp(a.dev_nodes.data(), b.dev_nodes.data(), a.dev_nodes.size() * sizeof(DevNode)) != 0) {
-    err = "layout self-test: the flat binary-node pass differs from the recursive one";
-    return RAYCA_ERR_BAD_ARG;
-  }
-  if (ref4[0] != ref4[1] || need4[0] != need4[1] || a.dev_nodes4.size() != b.dev_nodes4.size() ||
-      std::memcmp(a.dev_nodes4.data(), b.dev_nodes4.data(), a.dev_nodes4.size() * sizeof(DevNode4)) != 0) {
-    err = "layout self-test: the parallel 4-wide collapse differs from the sequential one";
-    return RAYCA_ERR_BAD_ARG;
+  for (const float node_cost : {0.0f, kLeafNodeCost}) {   // the tree as built, and with subtrees laid out as single leaves
+    HostScene a, b;
+    uint32_t ref[2], need[2], ref4[2], need4[2];
+    HostScene* scenes[2] = {&a, &b};
+    for (int pass = 0; pass < 2; ++pass) {
+      HostScene& s = *scenes[pass];
+      s.blas.push_back(bl);
+      DevBuilder db{s, {0u}};
+      db.node_cost = node_cost;
+      db.pad_rel = 1.52587890625e-05f;
+      db.pad_abs = 1e-6f;
+      db.allow_flat = pass == 1;
+      ref[pass] = db.emit_blas_node(s.blas[0], 0, 0, need[pass]);
+      WideBuilder wb{s};
+      wb.allow_parallel = pass == 1;
+      ref4[pass] = wb.build(ref[pass], need4[pass]);
+    }
+    if (node_cost == 0.0f && a.dev_nodes.size() < 65536) { err = "layout self-test: the random tree came out too small to exercise the parallel passes"; return RAYCA_ERR_BAD_ARG; }
+    if (ref[0] != ref[1] || need[0] != need[1] || a.dev_nodes.size() != b.dev_nodes.size() ||
+        std::memcmp(a.dev_nodes.data(), b.dev_nodes.data(), a.dev_nodes.size() * sizeof(DevNode)) != 0) {
+      err = "layout self-test: the flat binary-node pass differs from the recursive one";
+      return RAYCA_ERR_BAD_ARG;
+    }
+    if (ref4[0] != ref4[1] || need4[0] != need4[1] || a.dev_nodes4.size() != b.dev_nodes4.size() ||
+        std::memcmp(a.dev_nodes4.data(), b.dev_nodes4.data(), a.dev_nodes4.size() * sizeof(DevNode4)) != 0) {
+      err = "layout self-test: the parallel 4-wide collapse differs from the sequential one";
+      return RAYCA_ERR_BAD_ARG;
+    }
   }
   return RAYCA_OK;
 }
@@ -1262,6 +1304,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   // the traversed tree of a device-built BLAS stays on the device and is laid out there (HostBlas::dev_tree) -- unless the
   // other node formats are to be made right here, on the host, from the host's copy of the binary nodes
   const bool keep_trees = !hooks.with_formats;
+  // (RAYCA_LEAF_NODE_COST: experiments with the price of a node step, 0 lays the tree out as built)
+  static const float leaf_node_cost = [] { const char* e = getenv("RAYCA_LEAF_NODE_COST"); return e ? (float)atof(e) : kLeafNodeCost; }();
   void* const bstream[2] = {hooks.build_streams ? hooks.build_streams[0] : nullptr, hooks.build_streams ? hooks.build_streams[1] : nullptr};
   s.dev_segments.clear();
   s.dev_trees.clear();
@@ -1311,6 +1355,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       in.max_depth = 255u;
       in.device = device_ordinal;
       in.stream = stream;
+      in.layout_node_cost = seed_origin ? 0.0f : leaf_node_cost;
+      in.layout_leaf_max = kLeafCollapseMax;
       std::vector<uint32_t> perm;
       // (the arena as the host builder would have made it -- or, with `keep`, the tree left on the device and only its
       // root here)
@@ -1410,6 +1456,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     }
     s.pad_rel = db.pad_rel;
     s.pad_abs = db.pad_abs;
+    db.node_cost = builder == RAYCA_BUILDER_SAH ? leaf_node_cost : 0.0f;
     uint32_t base = 0;
     for (const HostBlas& bl : s.blas) {
       db.blas_base.push_back(base);

@@ -363,7 +363,7 @@ def test_sah_and_reference_builders_agree_at_full_size(gpu):
     desc = flatten(scenes.atrium_scene())
     a = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
     b = DeviceScene(desc, Config(), builder=abi.BUILDER_REFERENCE)
-    assert a.info()["node_count"] > 50 * b.info()["node_count"]   # the reference's tree barely splits
+    assert a.info()["node_count"] > 20 * b.info()["node_count"]   # the reference's tree barely splits (and the SAH layout folds pairs of triangles into one leaf)
     _, fa, _ = a.render(FLAT, 1920, 1080)
     _, fb, _ = b.render(FLAT, 1920, 1080)
     assert_exact(fa, fb)
@@ -446,10 +446,10 @@ def test_config3_soup_4096_full_size(gpu):
         formats.add(st["node_format"] & 5)
         assert np.array_equal(u8, first), (i, st["node_format"])
     assert formats == {0, 1, 4, 5} and not st["node_format"] & 256   # all four were used; the ninth frame is past calibration
-    # frames 9..12 time the two camera-ray kernels (fused generation kernel / lane refill) on the chosen format: same frame
+    # frames 9..16 time the two camera-ray kernels (fused generation kernel / lane refill) on the chosen format: same frame
     kernels = {bool(st["node_format"] & 1024)}
     assert st["node_format"] & 512
-    for i in range(3):
+    for i in range(7):
         u8, _, st = ds.render(FLAT, w, h, want_f32=False)
         assert st["node_format"] & 512 and np.array_equal(u8, first), (i, st["node_format"])
         kernels.add(bool(st["node_format"] & 1024))
