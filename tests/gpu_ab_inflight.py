@@ -25,7 +25,7 @@ for rnd in range(6):
         for n in names:
             ds = dss[n]
             for i in range(F):   # contexts warm, node format decided
-                for _ in range(2 if rnd else 6):
+                for _ in range(2 if rnd else 12):
                     ds.render_device(cfg, W, H, outs[i].data_ptr(), 0, stream=streams[i].cuda_stream, context=i, want_stats=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -429,8 +429,8 @@ def test_spheres(gpu, with_boxes):
 def test_config3_soup_4096_full_size(gpu):
     """BASELINE configs[3] at full size: 1 M random triangles at 4096x4096, primary rays.  Out of the oracle's reach,
     so checked through properties: culled front-to-back traversal == traversal of every leaf the reference visits;
-    the first nine frames of a scene cycle through the four node formats (binary / 4-wide, f32 / fp16) and must all be
-    the same frame; eight row tiles reassemble it."""
+    the first frames of a scene cycle through the four node formats (binary / 4-wide, f32 / fp16) and the two camera-ray
+    kernels and must all be the same frame; eight row tiles reassemble it."""
     w = h = 4096
     ds = DeviceScene(flatten(scenes.soup_scene()), Config(), builder=abi.BUILDER_SAH)
     # scene_create leaves the 4-wide / fp16 formats to a thread of its own: a frame issued before they are there runs on
@@ -440,20 +440,22 @@ def test_config3_soup_4096_full_size(gpu):
         assert not st["node_format"] & (5 | 256 | 512)
     print(f"[soup 4096^2] first frame issued {'before' if st['node_format'] & 2048 else 'after'} the other node formats were there")
     ds.finish()
-    formats = set()
-    for i in range(9):
+    # the next frames time the four node formats in turn (bit 8), then the two camera-ray kernels -- fused generation kernel /
+    # lane refill -- on the format that won (bit 9): every one of them must be the same frame
+    formats, kernels, n = set(), set(), 0
+    while True:
         u8, _, st = ds.render(FLAT, w, h, want_f32=False)
-        formats.add(st["node_format"] & 5)
-        assert np.array_equal(u8, first), (i, st["node_format"])
-    assert formats == {0, 1, 4, 5} and not st["node_format"] & 256   # all four were used; the ninth frame is past calibration
-    # frames 9..16 time the two camera-ray kernels (fused generation kernel / lane refill) on the chosen format: same frame
-    kernels = {bool(st["node_format"] & 1024)}
-    assert st["node_format"] & 512
-    for i in range(7):
-        u8, _, st = ds.render(FLAT, w, h, want_f32=False)
-        assert st["node_format"] & 512 and np.array_equal(u8, first), (i, st["node_format"])
-        kernels.add(bool(st["node_format"] & 1024))
-    assert kernels == {False, True}
+        assert np.array_equal(u8, first), (n, st["node_format"])
+        if st["node_format"] & 256:
+            assert not kernels, "a format calibration frame after the kernel calibration had begun"
+            formats.add(st["node_format"] & 5)
+        elif st["node_format"] & 512:
+            kernels.add(bool(st["node_format"] & 1024))
+        else:
+            break
+        n += 1
+        assert n < 100, "calibration does not end"
+    assert formats == {0, 1, 4, 5} and kernels == {False, True}, (formats, kernels)
     u8, _, st = ds.render(FLAT, w, h, want_f32=False, collect_stats=True)
     assert not st["node_format"] & (256 | 512) and np.array_equal(u8, first)
     print(f"[soup 4096^2] chosen: format bits {st['node_format'] & 5}, lane refill {bool(st['node_format'] & 1024)}, "
