@@ -32,6 +32,7 @@ if MODE == "last":
     fs, sp = frame_streams(dev, 8)
     early_streams = fs + sp
 parts_list = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+whole_ms = None
 for parts in parts_list:
     tile = (0, parts, 8)
     rows = ds.tile_rows(tile, H)
@@ -59,5 +60,8 @@ for parts in parts_list:
                         dist.gather(sends[i], recv, dst=0)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / K * 1e3
-            print(f"parts {parts} ({rows} rows) F={F} gather={'per frame' if gather else 'none':9s}: {ms:.4f} ms/frame  -> {parts}-GPU frame rate x{0.4475 / ms:.2f} of one GPU's", flush=True)
+            if parts == 1 and not gather:
+                whole_ms = ms   # one GPU's own frame time, measured here: what the shares are compared with
+            scale = f"x{whole_ms / ms:.2f} of one GPU's" if whole_ms else "(run with parts 1 first for the ratio)"
+            print(f"parts {parts} ({rows} rows) F={F} gather={'per frame' if gather else 'none':9s}: {ms:.4f} ms/frame  -> {parts}-GPU frame rate {scale}", flush=True)
 dist.destroy_process_group()
