@@ -297,6 +297,8 @@ def main():
     # kernel durations with HIP events on the launch stream (separate loop: the events force a sync per step)
     kms, tms = [], []
     launches_per_frame = 1
+    for _ in range(4):   # (the scene sizes its grids by the frame contexts of the last four calls: from here on there is one)
+        ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
     for _ in range(max(3, min(args.steps, 20))):
         st = ds.render_device(cfg, W, H, out.data_ptr(), 0, tile=tile, stream=stream.cuda_stream, want_stats=True)
         kms.append(st["kernel_ms"])
