@@ -1304,8 +1304,10 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   // the traversed tree of a device-built BLAS stays on the device and is laid out there (HostBlas::dev_tree) -- unless the
   // other node formats are to be made right here, on the host, from the host's copy of the binary nodes
   const bool keep_trees = !hooks.with_formats;
-  // (RAYCA_LEAF_NODE_COST: experiments with the price of a node step, 0 lays the tree out as built)
+  // (RAYCA_LEAF_NODE_COST / RAYCA_LEAF_MAX: experiments with the price of a node step -- 0 lays the tree out as built -- and
+  // with the cap on a folded leaf, which hardly ever binds: 4, 8, 16 and 32 give the same 135 379 nodes on the atrium)
   static const float leaf_node_cost = [] { const char* e = getenv("RAYCA_LEAF_NODE_COST"); return e ? (float)atof(e) : kLeafNodeCost; }();
+  static const uint32_t leaf_max = [] { const char* e = getenv("RAYCA_LEAF_MAX"); return e ? (uint32_t)std::min(std::max(atoi(e), 1), (int)kLeafMaxPrims) : kLeafCollapseMax; }();
   void* const bstream[2] = {hooks.build_streams ? hooks.build_streams[0] : nullptr, hooks.build_streams ? hooks.build_streams[1] : nullptr};
   s.dev_segments.clear();
   s.dev_trees.clear();
@@ -1356,7 +1358,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
       in.device = device_ordinal;
       in.stream = stream;
       in.layout_node_cost = seed_origin ? 0.0f : leaf_node_cost;
-      in.layout_leaf_max = kLeafCollapseMax;
+      in.layout_leaf_max = leaf_max;
       std::vector<uint32_t> perm;
       // (the arena as the host builder would have made it -- or, with `keep`, the tree left on the device and only its
       // root here)
@@ -1457,6 +1459,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     s.pad_rel = db.pad_rel;
     s.pad_abs = db.pad_abs;
     db.node_cost = builder == RAYCA_BUILDER_SAH ? leaf_node_cost : 0.0f;
+    db.leaf_max = leaf_max;
     uint32_t base = 0;
     for (const HostBlas& bl : s.blas) {
       db.blas_base.push_back(base);
