@@ -37,6 +37,9 @@ namespace rayca {
 namespace {
 
 constexpr int kB = 256;
+// k_build_level runs with 256 threads per node, and with 1024 on the levels that hold nodes above kBig primitives: their
+// partition is one workgroup's loop over the node's range (levels 0-4 of the atrium: 9.0 ms of the 14 with 256 threads)
+constexpr int kBuildLevelMaxBlock = 1024;
 constexpr uint32_t kBig = 16384;    // nodes above this size are binned by many workgroups (k_bin_big), kChunk positions each
 constexpr uint32_t kChunk = 4096;
 constexpr uint32_t kBinWords = 3 * 64 * 7;  // per node: count + min xyz + max xyz for 64 bins on 3 axes
@@ -97,7 +100,7 @@ __device__ __forceinline__ uint32_t block_prefix(bool flag, uint32_t* wave_tot, 
   if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
   __syncthreads();
   uint32_t before = 0, tot = 0;
-  for (uint32_t w = 0; w < kB / 64; ++w) {
+  for (uint32_t w = 0; w < blockDim.x / 64; ++w) {
     if (w < wave) before += wave_tot[w];
     tot += wave_tot[w];
   }
@@ -106,7 +109,7 @@ __device__ __forceinline__ uint32_t block_prefix(bool flag, uint32_t* wave_tot, 
 }
 
 __device__ __forceinline__ void init_bins(const DNode& nd, uint32_t (*s_cnt)[64], uint32_t (*s_min)[64][3], uint32_t (*s_max)[64][3], float (*s_pos)[64]) {
-  for (uint32_t i = threadIdx.x; i < 3 * 64; i += kB) {
+  for (uint32_t i = threadIdx.x; i < 3 * 64; i += blockDim.x) {
     const uint32_t a = i / 64, b = i % 64;
     s_cnt[a][b] = 0;
     for (int c = 0; c < 3; ++c) {
@@ -122,7 +125,7 @@ __device__ __forceinline__ void init_bins(const DNode& nd, uint32_t (*s_cnt)[64]
 // positions [begin, end) of the node's range into the 3 x 64 bins
 __device__ __forceinline__ void bin_range(const BuildState& st, const DNode& nd, const bool* valid, uint32_t (*s_cnt)[64], uint32_t (*s_min)[64][3],
                                           uint32_t (*s_max)[64][3], float (*s_pos)[64], uint32_t begin, uint32_t end) {
-  for (uint32_t s = begin + threadIdx.x; s < end; s += kB) {
+  for (uint32_t s = begin + threadIdx.x; s < end; s += blockDim.x) {
     const uint32_t id = st.order[nd.offset + s];
     float mn[3], mx[3];
     for (int c = 0; c < 3; ++c) {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chun
   bin_range(st, nd, valid, s_cnt, s_min, s_max, s_pos, begin, end);
   __syncthreads();
   uint32_t* g = st.gbins + (size_t)st.big[job.x] * kBinWords;
-  for (uint32_t i = threadIdx.x; i < 3 * 64; i += kB) {
+  for (uint32_t i = threadIdx.x; i < 3 * 64; i += blockDim.x) {
     const uint32_t a = i / 64, b = i % 64;
     if (s_cnt[a][b] == 0) continue;
     atomicAdd(&g[i * 7], s_cnt[a][b]);
@@ -188,12 +191,12 @@ __global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chun
   }
 }
 
-__global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level) {
+__global__ __launch_bounds__(kBuildLevelMaxBlock) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level) {
   __shared__ uint32_t s_cnt[3][64];
   __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
   __shared__ float s_pos[3][64];
   __shared__ float s_cost[3], s_split[3];
-  __shared__ uint32_t s_wave[kB / 64];
+  __shared__ uint32_t s_wave[kBuildLevelMaxBlock / 64];
   __shared__ uint32_t s_red[2][2][3];  // [child][min/max][xyz], encoded
   __shared__ int s_axis;
   __shared__ float s_best_pos;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
   const uint32_t nd_big = st.big[node_id];
   if (nd_big != RAYCA_NONE) {  // binned by k_bin_big: fetch
     const uint32_t* g = st.gbins + (size_t)nd_big * kBinWords;
-    for (uint32_t i = tid; i < 3 * 64; i += kB) {
+    for (uint32_t i = tid; i < 3 * 64; i += blockDim.x) {
       const uint32_t a = i / 64, b = i % 64;
       s_cnt[a][b] = g[i * 7];
       for (int c = 0; c < 3; ++c) {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
   const float* cax = st.cent[s_axis];
   const float pos = s_best_pos;
   uint32_t part = 0;
-  for (uint32_t s = tid; s < n; s += kB) part += cax[st.order[off + s]] < pos ? 1u : 0u;
+  for (uint32_t s = tid; s < n; s += blockDim.x) part += cax[st.order[off + s]] < pos ? 1u : 0u;
   atomicAdd(&s_left, part);
   __syncthreads();
   const uint32_t nl = s_left;
@@ -307,15 +310,15 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
     // everything on one side.  All left: the loop never swaps.  All right: it rotates the range (first element to
     // the end, the others down by one) -- and the node stays a leaf either way (blas.rs:291-293).
     if (nl == 0 && n > 1) {
-      for (uint32_t s = tid; s < n; s += kB) st.tmp[off + (s == 0 ? n - 1 : s - 1)] = st.order[off + s];
+      for (uint32_t s = tid; s < n; s += blockDim.x) st.tmp[off + (s == 0 ? n - 1 : s - 1)] = st.order[off + s];
       __syncthreads();
-      for (uint32_t s = tid; s < n; s += kB) st.order[off + s] = st.tmp[off + s];
+      for (uint32_t s = tid; s < n; s += blockDim.x) st.order[off + s] = st.tmp[off + s];
     }
     return;
   }
   // holes: right-class at p < nl, ranked ascending
   uint32_t run = 0;
-  for (uint32_t base = 0; base < nl; base += kB) {
+  for (uint32_t base = 0; base < nl; base += blockDim.x) {
     const uint32_t p = base + tid;
     const bool is_hole = p < nl && !(cax[st.order[off + p]] < pos);
     uint32_t tot;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
   const uint32_t K = run;  // holes == fillers
   // fillers: left-class at p >= nl, ranked descending
   run = 0;
-  for (uint32_t base = 0; base < n - nl; base += kB) {
+  for (uint32_t base = 0; base < n - nl; base += blockDim.x) {
     const uint32_t q = base + tid;            // distance from the end
     const bool in = q < n - nl;
     const uint32_t p = in ? n - 1 - q : 0;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
     run += tot;
   }
   __syncthreads();
-  for (uint32_t p = tid; p < n; p += kB) {
+  for (uint32_t p = tid; p < n; p += blockDim.x) {
     const uint32_t id = st.order[off + p];
     const bool left = cax[id] < pos;
     uint32_t dest;
@@ -363,14 +366,14 @@ __global__ __launch_bounds__(kB) void k_build_level(BuildState st, const uint32_
     st.tmp[off + dest] = id;
   }
   __syncthreads();
-  for (uint32_t p = tid; p < n; p += kB) st.order[off + p] = st.tmp[off + p];
+  for (uint32_t p = tid; p < n; p += blockDim.x) st.order[off + p] = st.tmp[off + p];
   // ---- 4. children --------------------------------------------------------------------------------------------------
   if (tid < 12) {
     const uint32_t child = tid / 6, mm = (tid / 3) & 1u, c = tid % 3;
     s_red[child][mm][c] = mm ? enc(-FLT_MAX) : enc(FLT_MAX);
   }
   __syncthreads();
-  for (uint32_t p = tid; p < n; p += kB) {
+  for (uint32_t p = tid; p < n; p += blockDim.x) {
     const uint32_t id = st.tmp[off + p];
     const uint32_t child = p < nl ? 0u : 1u;
     for (int c = 0; c < 3; ++c) {
@@ -857,7 +860,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     }
     HB_TRY(hipMemsetAsync(next_count, 0, 4, stream));
     HB_TRY(hipMemsetAsync(st.chunk_count, 0, 8, stream));  // chunk_count, slot_count
-    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(kB), 0, stream, st, lists[level & 1], lists[(level + 1) & 1], next_count,
+    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(n_chunks ? kBuildLevelMaxBlock : kB), 0, stream, st, lists[level & 1], lists[(level + 1) & 1], next_count,
                        st.chunks[(level + 1) & 1], level);
     HB_TRY(hipGetLastError());
     uint32_t counters[5];
