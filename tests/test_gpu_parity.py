@@ -416,6 +416,16 @@ def test_spheres(gpu, with_boxes):
         ou8, of32, ost = orc.render(cfg, 256, 256)
         assert_close(f32, of32, u8, ou8)
         assert st["rays_shadow"] == ost["rays_shadow"]
+        if builder == abi.BUILDER_SAH:
+            # four generations: the split engine, whose bounce rays and bounce shadow rays run on the lane-refill kernels
+            # (refill.hip, sphere instantiations) -- against the oracle, and against the fused kernels bit for bit
+            cfg4 = Config(max_depth=4)
+            _, f4, st4 = ds.render(cfg4, 192, 192, collect_stats=True)
+            _, of4, ost4 = orc.render(cfg4, 192, 192)
+            check_outliers(f"spheres_depth4_{'boxes' if with_boxes else 'alone'}", f4, of4)
+            assert st4["rays_shadow"] == ost4["rays_shadow"] and st4["rays_bounce"] == ost4["rays_bounce"]
+            _, ff, _ = ds.render(cfg4, 192, 192, engine=abi.ENGINE_FUSED)
+            assert_exact(f4, ff)
         if builder == abi.BUILDER_REFERENCE:
             rs = np.random.RandomState(3)
             o = rs.uniform(-4, 4, (256, 3)).astype(np.float32)
