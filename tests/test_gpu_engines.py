@@ -204,3 +204,25 @@ def test_lane_refill_at_full_size_and_its_lane_utilisation(gpu):
     with pytest.raises(Exception):
         ds.render(flat, 64, 64, camera_rays=7)
     ds.close()
+
+
+def test_scene_lifetime_around_the_background_formats(gpu):
+    """scene_create leaves the 4-wide / fp16 node formats to a thread of the scene's own.  A scene may be destroyed at any
+    point of that thread's life (it stops at its next phase boundary), frames issued before the formats are there run on
+    the binary nodes, and the frame is the same before and after."""
+    desc = flatten(scenes.atrium_scene())
+    cfg = Config(max_depth=1)
+    DeviceScene(desc, Config(), builder=abi.BUILDER_SAH).close()            # destroyed at once, not a frame rendered
+    ds = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
+    early, _, st = ds.render(cfg, 640, 360, want_f32=False, collect_stats=True)
+    ds.close()                                                               # destroyed while the thread may still be running
+    ds = DeviceScene(desc, Config(), builder=abi.BUILDER_SAH)
+    ds.finish()
+    info = ds.info()
+    assert info["node_count"] > 0 and info["triangle_count"] == 271568
+    late, _, st2 = ds.render(cfg, 640, 360, want_f32=False, collect_stats=True)
+    assert not st2["node_format"] & 2048
+    assert np.array_equal(early, late)
+    assert st["boxes_tested"] > 0 and st2["triangles_tested"] > 0
+    ds.finish()                                                              # a second wait is a no-op
+    ds.close()
