@@ -226,3 +226,27 @@ def test_scene_lifetime_around_the_background_formats(gpu):
     assert st["boxes_tested"] > 0 and st2["triangles_tested"] > 0
     ds.finish()                                                              # a second wait is a no-op
     ds.close()
+
+
+def test_frame_streams_helper(gpu):
+    """rayca_amd.streams.frame_streams: the last streams of one run of pool streams, all different, and frames issued on them
+    with one frame context each come out as the frame rendered alone."""
+    import torch
+    from rayca_amd.streams import frame_streams
+    dev = torch.device("cuda", 0)
+    frames, spares = frame_streams(dev, 4, spare=1)
+    handles = [s.cuda_stream for s in frames + spares]
+    assert len(frames) == 4 and len(spares) == 1 and len(set(handles)) == 5
+    with pytest.raises(ValueError):
+        frame_streams(dev, 16, spare=1)
+    ds = DeviceScene(flatten(scenes.cornell_scene()), Config())
+    cfg = Config(max_depth=2)
+    alone, _, _ = ds.render(cfg, 320, 180, want_f32=False)
+    outs = [torch.zeros((180, 320, 4), dtype=torch.uint8, device=dev) for _ in frames]
+    for rnd in range(3):
+        for i, s in enumerate(frames):
+            ds.render_device(cfg, 320, 180, outs[i].data_ptr(), 0, stream=s.cuda_stream, context=i)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), alone)
+    ds.close()
