@@ -599,12 +599,11 @@ struct LayoutState {
   const DNode* nodes;
   uint32_t node_count;
   uint32_t* parent;   // arena index of the parent, RAYCA_NONE for the root
-  uint32_t* size;     // DevNodes of the subtree
-  uint32_t* need;     // pending stack entries of a traversal of the subtree
+  uint4* rec;         // per node: x = DevNodes of the subtree, y = pending stack entries of a traversal of it, z = primitives
+                      // below it, w = bits of its expected cost as laid out (triangle tests x box area) -- one 16-B record,
+                      // written once by the thread that finishes the node and read by the one that finishes its parent
   uint32_t* arrived;  // children that have reported to this node
   uint32_t* index;    // layout index of the node (of the head of its chain), root = 0
-  uint32_t* prims;    // primitives below the node
-  float* cost;        // expected cost of traversing the subtree as it is laid out, in triangle tests x box area
   uint32_t* leafed;   // 1: the subtree is laid out as ONE leaf (its primitives are a contiguous range of the order)
   // subtrees that are no dearer as one leaf are laid out as one (host_scene.hpp kLeafNodeCost; the same arithmetic as
   // DevBuilder::plan_leaves on the host); node_cost 0: the tree as built
@@ -630,30 +629,21 @@ __global__ void k_layout_sizes(LayoutState ls) {
   const DNode nd = ls.nodes[i];
   if (nd.left >= 0) return;  // leaves start the climb
   const uint32_t chain = chain_nodes(nd.count);
-  __hip_atomic_store(&ls.size[i], chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (device-scope accesses: another CU reads them)
-  __hip_atomic_store(&ls.need[i], chain ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&ls.prims[i], nd.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&ls.cost[i], (float)nd.count * area3(nd.a, nd.b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ls.rec[i] = make_uint4(chain, chain ? 1u : 0u, nd.count, __float_as_uint((float)nd.count * area3(nd.a, nd.b)));
   ls.leafed[i] = 0u;
-  __threadfence();
   uint32_t p = ls.parent[i];
   while (p != RAYCA_NONE) {
-    if (atomicAdd(&ls.arrived[p], 1u) == 0u) return;  // the sibling subtree is not finished: its last thread goes on
-    __threadfence();
+    // release: the record above (or the one written at the end of the last trip) is visible before the count is; acquire:
+    // the second child to arrive sees its sibling's record
+    if (__hip_atomic_fetch_add(&ls.arrived[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // the sibling subtree is not finished: its last thread goes on
     const DNode pn = ls.nodes[p];
-    const uint32_t sl = __hip_atomic_load(&ls.size[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sr = __hip_atomic_load(&ls.size[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t nl = __hip_atomic_load(&ls.need[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nr = __hip_atomic_load(&ls.need[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t pl = __hip_atomic_load(&ls.prims[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pr = __hip_atomic_load(&ls.prims[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float cl = __hip_atomic_load(&ls.cost[pn.left], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cr = __hip_atomic_load(&ls.cost[pn.right], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float area = area3(pn.a, pn.b), as_leaf = (float)(pl + pr) * area, as_split = ls.node_cost * area + cl + cr;
+    const uint4 l = ls.rec[pn.left], r = ls.rec[pn.right];
+    const uint32_t pl = l.z, pr = r.z;
+    const float area = area3(pn.a, pn.b), as_leaf = (float)(pl + pr) * area, as_split = ls.node_cost * area + __uint_as_float(l.w) + __uint_as_float(r.w);
     // (the whole subtree becomes one leaf reference in its parent: no nodes of its own)
     const bool one_leaf = ls.node_cost > 0.0f && pl + pr <= ls.leaf_max && as_leaf <= as_split;
     ls.leafed[p] = one_leaf ? 1u : 0u;
-    __hip_atomic_store(&ls.cost[p], one_leaf ? as_leaf : as_split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ls.prims[p], pl + pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ls.size[p], one_leaf ? 0u : 1u + sl + sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ls.need[p], one_leaf ? 0u : 1u + (nl > nr ? nl : nr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    ls.rec[p] = make_uint4(one_leaf ? 0u : 1u + l.x + r.x, one_leaf ? 0u : 1u + (l.y > r.y ? l.y : r.y), pl + pr, __float_as_uint(one_leaf ? as_leaf : as_split));
     p = ls.parent[p];
   }
 }
@@ -664,7 +654,7 @@ __global__ void k_layout_index(LayoutState ls) {
   bool inside = false;   // below a subtree that is laid out as one leaf: this node is not laid out at all
   for (uint32_t p = ls.parent[c]; p != RAYCA_NONE; p = ls.parent[c]) {
     const DNode pn = ls.nodes[p];
-    idx += 1u + ((uint32_t)pn.right == c ? ls.size[pn.left] : 0u);
+    idx += 1u + ((uint32_t)pn.right == c ? ls.rec[pn.left].x : 0u);
     inside = inside || ls.leafed[p] != 0u;
     c = p;
   }
@@ -703,7 +693,7 @@ __global__ void k_layout_emit(LayoutState ls, DevNode* out, uint32_t first, uint
     for (int c = 0; c < 2; ++c) {
       const DNode& k = *kids[c];
       const uint32_t ki = (uint32_t)(c ? nd.right : nd.left);
-      if (k.left >= 0) refs[c] = ls.leafed[ki] == 1u ? layout_leaf_ref(prim_base + k.offset, ls.prims[ki]) : first + ls.index[ki];
+      if (k.left >= 0) refs[c] = ls.leafed[ki] == 1u ? layout_leaf_ref(prim_base + k.offset, ls.rec[ki].z) : first + ls.index[ki];
       else if (k.count == 0u) refs[c] = kNoChild;
       else refs[c] = k.count <= kLeafMaxPrims ? layout_leaf_ref(prim_base + k.offset, k.count) : first + ls.index[ki];
     }
@@ -895,9 +885,9 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     LayoutState ls{};
     ls.nodes = st.nodes;
     ls.node_count = node_count;
-    uint32_t** parts[7] = {&ls.parent, &ls.size, &ls.need, &ls.arrived, &ls.index, &ls.prims, &ls.leafed};
-    for (int i = 0; i < 7; ++i) *parts[i] = reinterpret_cast<uint32_t*>(base + off_layout[i]);
-    ls.cost = reinterpret_cast<float*>(base + off_layout[7]);
+    uint32_t** parts[4] = {&ls.parent, &ls.arrived, &ls.index, &ls.leafed};
+    for (int i = 0; i < 4; ++i) *parts[i] = reinterpret_cast<uint32_t*>(base + off_layout[i]);
+    ls.rec = reinterpret_cast<uint4*>(base + off_layout[4]);   // (four words per node: off_layout[4..7], contiguous and 256-B aligned)
     ls.node_cost = in.layout_node_cost;
     ls.leaf_max = std::min<uint32_t>(std::max<uint32_t>(in.layout_leaf_max, 1u), kLeafMaxPrims);
     const dim3 grid((node_count + kB - 1) / kB), block(kB);
@@ -905,9 +895,8 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     hipLaunchKernelGGL(k_layout_sizes, grid, block, 0, stream, ls);
     hipLaunchKernelGGL(k_layout_index, grid, block, 0, stream, ls);
     HB_TRY(hipGetLastError());
-    uint32_t root_size = 0, root_need = 0;
-    HB_TRY(hipMemcpyAsync(&root_size, ls.size, 4, hipMemcpyDeviceToHost, stream));
-    HB_TRY(hipMemcpyAsync(&root_need, ls.need, 4, hipMemcpyDeviceToHost, stream));
+    uint32_t root_rec[4] = {0, 0, 0, 0};
+    HB_TRY(hipMemcpyAsync(root_rec, ls.rec, sizeof root_rec, hipMemcpyDeviceToHost, stream));
     order.resize(n);
     HB_TRY(hipMemcpyAsync(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream));
     HB_TRY(hipStreamSynchronize(stream));
@@ -921,8 +910,8 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     pool = nullptr;     // (cleanup() below must not release what the handle now owns)
     stream = nullptr;
     keep->handle = kt;
-    keep->node_count = root_size;
-    keep->need = root_need;
+    keep->node_count = root_rec[0];
+    keep->need = root_rec[1];
     return true;
   }
   arena.resize(node_count);   // DNode == BuildNode (asserted above): no conversion pass
