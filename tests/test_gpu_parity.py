@@ -450,17 +450,17 @@ def test_config3_soup_4096_full_size(gpu):
         assert not st["node_format"] & (5 | 256 | 512)
     print(f"[soup 4096^2] first frame issued {'before' if st['node_format'] & 2048 else 'after'} the other node formats were there")
     ds.finish()
-    # the next frames time the four node formats in turn (bit 8), then the two camera-ray kernels -- fused generation kernel /
-    # lane refill -- on the format that won (bit 9): every one of them must be the same frame
+    # the next frames time the two camera-ray kernels -- fused generation kernel / lane refill (bit 9) -- and then the four
+    # node formats in turn on the kernel that won (bit 8): every one of them must be the same frame
     formats, kernels, n = set(), set(), 0
     while True:
         u8, _, st = ds.render(FLAT, w, h, want_f32=False)
         assert np.array_equal(u8, first), (n, st["node_format"])
-        if st["node_format"] & 256:
-            assert not kernels, "a format calibration frame after the kernel calibration had begun"
-            formats.add(st["node_format"] & 5)
-        elif st["node_format"] & 512:
+        if st["node_format"] & 512:
+            assert not formats, "a kernel calibration frame after the format calibration had begun"
             kernels.add(bool(st["node_format"] & 1024))
+        elif st["node_format"] & 256:
+            formats.add(st["node_format"] & 5)
         else:
             break
         n += 1
