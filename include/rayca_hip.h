@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define RAYCA_ABI_VERSION 1u
+#define RAYCA_ABI_VERSION 2u   /* 2: RaycaRenderOptions.wait_event / record_event, RaycaStats.class_ms / class_launches,
+                                  RaycaMultiOptions.context, rayca_hip_render_multi_issue / _wait */
 #define RAYCA_NONE 0xFFFFFFFFu /* Handle::NONE, rayca-util/src/pack.rs:61-64 */
 
 /* ---- status codes -------------------------------------------------------------------------- */
@@ -324,8 +325,26 @@ typedef struct RaycaRenderOptions {
    * context are serialised.  The scene (BVH, triangles, materials) is shared. */
   uint32_t context;
   uint32_t camera_rays;   /* RAYCA_CAMERA_* */
-  uint32_t reserved;
+  uint32_t reserved;      /* must be zero (as every `reserved` field of this header) */
+  /* Two hipEvent_t handles (or NULL), so that a frame loop needs ONE call per frame: the frame's stream waits for
+   * `wait_event` before its first kernel (e.g. "the previous gather out of this buffer has finished") and `record_event`
+   * is recorded on it behind the last one (e.g. for the comm stream to wait on).  rayca_hip_render_device only. */
+  void* wait_event;
+  void* record_event;
 } RaycaRenderOptions;
+
+/* Kernel classes RaycaStats.class_ms / class_launches are indexed by */
+enum {
+  RAYCA_KERNEL_GENERATION = 0,    /* k_generation: the fused persistent kernel of a generation (kernels.hip)        */
+  RAYCA_KERNEL_FLAT_REFILL = 1,   /* k_flat_refill: camera rays with lane refill (refill.hip)                        */
+  RAYCA_KERNEL_WF_TRACE = 2,      /* k_wf_trace: closest hits, one ray per lane (wavefront.inc)                      */
+  RAYCA_KERNEL_QUEUE_REFILL = 3,  /* k_queue_refill: closest hits of a bounce generation, lane refill (refill.hip)   */
+  RAYCA_KERNEL_WF_SHADE = 4,      /* k_wf_shade: shading, NEE set-up, bounce sampling (wavefront.inc)                */
+  RAYCA_KERNEL_WF_SHADOW = 5,     /* k_wf_shadow: shadow rays + direct sum, one pixel per lane (wavefront.inc)       */
+  RAYCA_KERNEL_SHADOW_REFILL = 6, /* k_shadow_refill: the same with lane refill (refill.hip)                         */
+  RAYCA_KERNEL_OTHER = 7,         /* k_general (the stack machine), k_resolve, k_trace_rays                          */
+  RAYCA_KERNEL_CLASSES = 8
+};
 
 /* Filled by every render call (all counters are per call, summed over spp and generations). */
 typedef struct RaycaStats {
@@ -349,11 +368,17 @@ typedef struct RaycaStats {
   /* node format of this frame's launches: bit 0 = generation 0 used 4-wide nodes, bit 1 = the bounce
    * generations did, bits 2 / 3 = the same for fp16 node boxes, bit 8 = this was a calibration frame (the scene
    * is still timing the formats), bit 9 = a calibration frame of the camera-ray kernel choice (Flat frames: fused
-   * generation kernel or lane-refill kernel, timed once the format is settled), bit 10 = this frame's camera rays ran on
+   * generation kernel or lane-refill kernel, timed FIRST, on 4-wide f32 nodes; the node formats are timed afterwards on
+   * the kernel that won), bit 10 = this frame's camera rays ran on
    * the lane-refill kernel, bit 11 = the scene's 4-wide / fp16 node formats were still being made when this frame was
    * issued (a thread started by rayca_hip_scene_create encodes and uploads them; until then frames traverse the binary
    * f32 nodes and nothing is timed -- same pixels either way) */
   uint32_t node_format;
+  /* HIP-event time (ms, summed over the launches of the call) and number of launches per kernel class (RAYCA_KERNEL_*):
+   * class_ms[k] / class_launches[k] is the live average launch duration of that kernel -- what bench.py prices its
+   * roofline with, and what the rocprofv3 kernel trace of the same command must agree with. */
+  float class_ms[8];
+  uint32_t class_launches[8];
 } RaycaStats;
 
 typedef struct RaycaSceneInfo {
@@ -438,16 +463,32 @@ typedef struct RaycaMultiOptions {
   uint32_t gather;           /* RAYCA_GATHER_* */
   uint32_t engine;           /* RAYCA_ENGINE_* */
   uint32_t output_on_device; /* 1: rgba8_out is device memory of scenes[0]'s device, 0: host memory */
-  uint32_t reserved[2];
+  uint32_t context;          /* frame context 0..7 of every scene (RaycaRenderOptions.context): frames issued with different
+                                contexts overlap on the devices (rayca_hip_render_multi_issue) */
+  uint32_t reserved;
 } RaycaMultiOptions;
 
 /* One frame on `count` devices.  scenes[i] is a handle created (from the same RaycaSceneDesc) on the device that renders
  * part i; scenes[0]'s device assembles the frame.  rgba8_out receives width x height RGBA8 (host memory unless
  * opts->output_on_device).  stats_out: NULL or `count` entries, one per device.  count == 1 is rayca_hip_render.
- * Synchronous.  Uses frame context 0 of every scene. */
+ * Synchronous: rayca_hip_render_multi_issue + rayca_hip_render_multi_wait on frame context opts->context. */
 int32_t rayca_hip_render_multi(RaycaScene* const* scenes, uint32_t count, const RaycaConfig* cfg, uint32_t width,
                                uint32_t height, const RaycaMultiOptions* opts, void* rgba8_out,
                                RaycaStats* stats_out);
+
+/* The same frame, asynchronously: queues the rendering of every part (frame context opts->context of every scene, each on
+ * that context's own stream), the one exchange, the de-interleave and the copy into rgba8_out, and returns.  A host that
+ * issues frames with contexts 0, 1, 2, 3 in turn and waits for a context only before it re-uses it keeps four frames in
+ * flight on every device -- the tail of one frame then runs under the head of the next, which is what a frame-at-a-time
+ * loop leaves on the table (one GPU, 1080p primary + shadow: 0.51 -> 0.38 ms per frame; a rank's eighth 0.19 -> 0.06 ms).
+ * rgba8_out (and host memory it points to) must stay valid until the matching wait.  Frames of one context are
+ * serialised.  No statistics (they need a synchronisation per frame: use rayca_hip_render_multi).
+ * The drop-in host loop (draw.rs:7-9 called per frame) is `issue(ctx = f % 4)`, `wait(ctx = (f + 1) % 4)`. */
+int32_t rayca_hip_render_multi_issue(RaycaScene* const* scenes, uint32_t count, const RaycaConfig* cfg, uint32_t width,
+                                     uint32_t height, const RaycaMultiOptions* opts, void* rgba8_out);
+/* Waits until the frame last issued with frame context `context` on these scenes has landed in its rgba8_out; returns
+ * that frame's status.  RAYCA_OK at once if there is none. */
+int32_t rayca_hip_render_multi_wait(RaycaScene* const* scenes, uint32_t count, uint32_t context);
 
 /* RAYCA_OK if librccl can be opened and offers what RAYCA_GATHER_RCCL uses, else RAYCA_ERR_RCCL with the reason in
  * rayca_hip_last_error.  Needs no GPU. */

@@ -253,6 +253,7 @@ struct Decoder {
   // one scan; returns the position behind its entropy-coded data
   size_t scan(size_t pos) {
     const int len = be16(data + pos);
+    if (len < 6 || pos + (size_t)len > size) bad("bad scan header");   // (before its first byte is read)
     const uint8_t* p = data + pos + 2;
     const int ns = p[0];
     if (ns < 1 || ns > (int)comps.size() || len != 6 + 2 * ns) bad("bad scan header");

@@ -22,7 +22,7 @@ use std::os::raw::{c_char, c_void};
 
 use crate::*;
 
-pub const RAYCA_ABI_VERSION: u32 = 1;
+pub const RAYCA_ABI_VERSION: u32 = 2;
 pub const RAYCA_NONE: u32 = 0xFFFF_FFFF; // Handle::NONE, rayca-util/src/pack.rs:61-64
 
 // ---- status codes ---------------------------------------------------------------------------------------------------
@@ -60,6 +60,16 @@ pub const RAYCA_ENGINE_FUSED: u32 = 3;
 pub const RAYCA_CAMERA_AUTO: u32 = 0;
 pub const RAYCA_CAMERA_GENERATION: u32 = 1;
 pub const RAYCA_CAMERA_REFILL: u32 = 2;
+// RaycaStats.class_ms / class_launches
+pub const RAYCA_KERNEL_GENERATION: u32 = 0;
+pub const RAYCA_KERNEL_FLAT_REFILL: u32 = 1;
+pub const RAYCA_KERNEL_WF_TRACE: u32 = 2;
+pub const RAYCA_KERNEL_QUEUE_REFILL: u32 = 3;
+pub const RAYCA_KERNEL_WF_SHADE: u32 = 4;
+pub const RAYCA_KERNEL_WF_SHADOW: u32 = 5;
+pub const RAYCA_KERNEL_SHADOW_REFILL: u32 = 6;
+pub const RAYCA_KERNEL_OTHER: u32 = 7;
+pub const RAYCA_KERNEL_CLASSES: u32 = 8;
 pub const RAYCA_GATHER_RCCL: u32 = 0;
 pub const RAYCA_GATHER_PEER_COPY: u32 = 1;
 
@@ -239,6 +249,8 @@ pub struct RaycaRenderOptions {
     pub context: u32,
     pub camera_rays: u32,
     pub reserved: u32,
+    pub wait_event: *mut c_void,
+    pub record_event: *mut c_void,
 }
 
 #[repr(C)]
@@ -250,7 +262,8 @@ pub struct RaycaMultiOptions {
     pub gather: u32,
     pub engine: u32,
     pub output_on_device: u32,
-    pub reserved: [u32; 2],
+    pub context: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -270,6 +283,8 @@ pub struct RaycaStats {
     pub trace_kernel_launches: u32,
     pub rows_rendered: u32,
     pub node_format: u32,
+    pub class_ms: [f32; 8],
+    pub class_launches: [u32; 8],
 }
 
 #[repr(C)]
@@ -305,6 +320,8 @@ extern "C" {
     pub fn rayca_hip_render(scene: *mut RaycaScene, cfg: *const RaycaConfig, width: u32, height: u32, opts: *const RaycaRenderOptions, rgba8_out: *mut u8, rgba32f_out: *mut f32, stats_out: *mut RaycaStats) -> i32;
     pub fn rayca_hip_render_device(scene: *mut RaycaScene, cfg: *const RaycaConfig, width: u32, height: u32, opts: *const RaycaRenderOptions, d_rgba8_out: *mut c_void, d_rgba32f_out: *mut c_void, stats_out: *mut RaycaStats) -> i32;
     pub fn rayca_hip_render_multi(scenes: *const *mut RaycaScene, count: u32, cfg: *const RaycaConfig, width: u32, height: u32, opts: *const RaycaMultiOptions, rgba8_out: *mut c_void, stats_out: *mut RaycaStats) -> i32;
+    pub fn rayca_hip_render_multi_issue(scenes: *const *mut RaycaScene, count: u32, cfg: *const RaycaConfig, width: u32, height: u32, opts: *const RaycaMultiOptions, rgba8_out: *mut c_void) -> i32;
+    pub fn rayca_hip_render_multi_wait(scenes: *const *mut RaycaScene, count: u32, context: u32) -> i32;
     pub fn rayca_hip_rccl_status() -> i32;
     pub fn rayca_hip_tile_rows(tile: *const RaycaTile, height: u32) -> u32;
     pub fn rayca_hip_trace_rays(scene: *mut RaycaScene, opts: *const RaycaRenderOptions, count: u32, rays: *const f32, t_out: *mut f32, prim_out: *mut u32, uv_out: *mut f32, stats_out: *mut RaycaStats) -> i32;

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NONE = 0xFFFFFFFF
 
 # status codes
@@ -38,6 +38,9 @@ BUILDER_REFERENCE, BUILDER_SAH = 0, 1
 ENGINE_AUTO, ENGINE_GENERAL, ENGINE_WAVEFRONT, ENGINE_FUSED = 0, 1, 2, 3
 TRAVERSAL_ORDERED, TRAVERSAL_EXHAUSTIVE = 0, 1
 CAMERA_AUTO, CAMERA_GENERATION, CAMERA_REFILL = 0, 1, 2
+# RaycaStats.class_ms / class_launches
+KERNEL_GENERATION, KERNEL_FLAT_REFILL, KERNEL_WF_TRACE, KERNEL_QUEUE_REFILL, KERNEL_WF_SHADE, KERNEL_WF_SHADOW, KERNEL_SHADOW_REFILL, KERNEL_OTHER = range(8)
+KERNEL_NAMES = ("k_generation", "k_flat_refill", "k_wf_trace", "k_queue_refill", "k_wf_shade", "k_wf_shadow", "k_shadow_refill", "other")
 GATHER_RCCL, GATHER_PEER_COPY = 0, 1
 
 
@@ -195,6 +198,8 @@ class RaycaRenderOptions(C.Structure):
         ("context", C.c_uint32),
         ("camera_rays", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("wait_event", C.c_void_p),
+        ("record_event", C.c_void_p),
     ]
 
 
@@ -206,7 +211,8 @@ class RaycaMultiOptions(C.Structure):
         ("gather", C.c_uint32),
         ("engine", C.c_uint32),
         ("output_on_device", C.c_uint32),
-        ("reserved", C.c_uint32 * 2),
+        ("context", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -226,10 +232,12 @@ class RaycaStats(C.Structure):
         ("trace_kernel_launches", C.c_uint32),
         ("rows_rendered", C.c_uint32),
         ("node_format", C.c_uint32),
+        ("class_ms", C.c_float * 8),
+        ("class_launches", C.c_uint32 * 8),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.startswith("class_") else getattr(self, n)) for n, _ in self._fields_}
 
 
 class RaycaSceneInfo(C.Structure):
@@ -368,6 +376,10 @@ def bind_product_signatures(lib):
     lib.rayca_hip_render_multi.restype = C.c_int32
     lib.rayca_hip_render_multi.argtypes = [P(C.c_void_p), C.c_uint32, P(RaycaConfig), C.c_uint32, C.c_uint32, P(RaycaMultiOptions),
                                            C.c_void_p, P(RaycaStats)]
+    lib.rayca_hip_render_multi_issue.restype = C.c_int32
+    lib.rayca_hip_render_multi_issue.argtypes = [P(C.c_void_p), C.c_uint32, P(RaycaConfig), C.c_uint32, C.c_uint32, P(RaycaMultiOptions), C.c_void_p]
+    lib.rayca_hip_render_multi_wait.restype = C.c_int32
+    lib.rayca_hip_render_multi_wait.argtypes = [P(C.c_void_p), C.c_uint32, C.c_uint32]
     return lib
 
 
@@ -375,5 +387,6 @@ PRODUCT_SYMBOLS = [
     "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_selftest", "rayca_hip_last_error", "rayca_hip_config_default",
     "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_info", "rayca_hip_scene_finish", "rayca_hip_render",
     "rayca_hip_render_device", "rayca_hip_tile_rows", "rayca_hip_trace_rays",
-    "rayca_hip_scene_primitive_order", "rayca_hip_render_multi", "rayca_hip_rccl_status",
+    "rayca_hip_scene_primitive_order", "rayca_hip_render_multi", "rayca_hip_render_multi_issue", "rayca_hip_render_multi_wait",
+    "rayca_hip_rccl_status",
 ]

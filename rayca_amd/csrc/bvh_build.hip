@@ -898,8 +898,9 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
     uint32_t root_rec[4] = {0, 0, 0, 0};
     HB_TRY(hipMemcpyAsync(root_rec, ls.rec, sizeof root_rec, hipMemcpyDeviceToHost, stream));
     order.resize(n);
-    HB_TRY(hipMemcpyAsync(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream));
+    HB_TRY(staged.copy_back(order.data(), st.order, sizeof(uint32_t) * n, stream));   // (through the staging blocks, like the uploads)
     HB_TRY(hipStreamSynchronize(stream));
+    staged.finish();
     lap("layout sizes + order");
     KeptTree* kt = new KeptTree();
     kt->pool = pool;
@@ -916,9 +917,10 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   }
   arena.resize(node_count);   // DNode == BuildNode (asserted above): no conversion pass
   order.resize(n);
-  HB_TRY(hipMemcpyAsync(static_cast<void*>(arena.data()), st.nodes, sizeof(DNode) * node_count, hipMemcpyDeviceToHost, stream));
-  HB_TRY(hipMemcpyAsync(order.data(), st.order, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, stream));
+  HB_TRY(staged.copy_back(static_cast<void*>(arena.data()), st.nodes, sizeof(DNode) * node_count, stream));
+  HB_TRY(staged.copy_back(order.data(), st.order, sizeof(uint32_t) * n, stream));
   HB_TRY(hipStreamSynchronize(stream));
+  staged.finish();
   lap("download");
   cleanup();
   lap("free");

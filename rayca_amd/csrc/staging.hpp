@@ -92,6 +92,46 @@ class StagedCopier {
     }
     return hipSuccess;
   }
+  // The other direction: dst[0, bytes) (host) <- src (device), in stream order behind what `stream` already holds.  The copy
+  // engine writes a block while the CPU empties the other; when it returns, `dst` is complete.  Like copy() it keeps the
+  // runtime from page-locking the library's own heap memory in place ("The fault of round 2").
+  hipError_t copy_back(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes < (size_t(256) << 10) || !ensure()) {   // (small: the runtime stages it through its own page-locked buffers)
+      hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      return e;
+    }
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2; ++k) {   // blocks still being read by an earlier copy() of this object
+      if (busy_[k] && (e = hipEventSynchronize(ev_[k])) != hipSuccess) return e;
+      busy_[k] = false;
+    }
+    size_t pending_off = 0, pending_n = 0;
+    int pending_k = -1;
+    auto drain = [&]() -> hipError_t {   // the chunk queued one step ago: wait for it, copy it out
+      if (pending_k < 0) return hipSuccess;
+      const hipError_t de = hipEventSynchronize(ev_[pending_k]);
+      if (de == hipSuccess) std::memcpy(static_cast<char*>(dst) + pending_off, block_[pending_k], pending_n);
+      pending_k = -1;
+      return de;
+    };
+    for (size_t off = 0; off < bytes; off += kStagingBlock) {
+      const size_t n = bytes - off < kStagingBlock ? bytes - off : kStagingBlock;
+      const int k = turn_;
+      turn_ ^= 1;
+      if ((e = hipMemcpyAsync(block_[k], static_cast<const char*>(src) + off, n, hipMemcpyDeviceToHost, stream)) != hipSuccess) break;
+      if ((e = hipEventRecord(ev_[k], stream)) != hipSuccess) break;
+      const hipError_t de = drain();   // (the previous chunk, while this one is in flight)
+      pending_off = off; pending_n = n; pending_k = k;
+      if (de != hipSuccess) { e = de; break; }
+    }
+    if (e != hipSuccess) {   // nothing may still be writing a block when it goes back to the cache
+      (void)hipStreamSynchronize(stream);
+      return e;
+    }
+    return drain();
+  }
   // Waits until the blocks are no longer being read and hands them back.
   void finish() {
     for (int k = 0; k < 2; ++k) {

@@ -126,13 +126,16 @@ class DeviceScene:
 
     def prepare_device(self, config: Config, width: int, height: int, d_rgba8: int, d_f32: int = 0, *,
                        traversal=abi.TRAVERSAL_ORDERED, tile=None, stream=None, engine=abi.ENGINE_AUTO, context=0,
-                       camera_rays=abi.CAMERA_AUTO):
+                       camera_rays=abi.CAMERA_AUTO, wait_event=None, record_event=None):
         """rayca_hip_render_device with every argument marshalled once: returns a zero-argument callable that issues the
         frame (asynchronously, no statistics).  A frame loop that renders the same frame into the same buffer again and
         again -- bench.py's ranks, a viewer -- pays the ctypes marshalling once instead of per frame (~10 us of the
         ~50 us a rank's share of a 1080p frame costs on the host)."""
         cfg = config.to_abi()
         o = self._opts(traversal, False, tile, stream, engine, context, camera_rays)
+        # hipEvent_t handles (ints): the frame's stream waits for the one before its first kernel and records the other
+        # behind its last -- wait + render + record in ONE native call (RaycaRenderOptions.wait_event / record_event)
+        o.wait_event, o.record_event = wait_event, record_event
         fn, handle, check = self._lib.rayca_hip_render_device, self.handle, lib.check
         args = (handle, C.byref(cfg), width, height, C.byref(o), d_rgba8 or None, d_f32 or None, None)
 
@@ -155,19 +158,51 @@ class DeviceScene:
         return t, prim, uv, st.as_dict()
 
 
+def _multi_args(scenes, config, band_rows, gather, traversal, collect_stats, engine, context):
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    o = abi.RaycaMultiOptions()
+    o.traversal, o.collect_stats, o.band_rows, o.gather, o.engine, o.context = traversal, int(collect_stats), band_rows, gather, engine, context
+    return handles, o, config.to_abi()
+
+
 def render_multi(scenes, config: Config, width: int, height: int, *, band_rows=8, gather=abi.GATHER_RCCL, traversal=abi.TRAVERSAL_ORDERED,
-                 collect_stats=False, engine=abi.ENGINE_AUTO, want_stats=False):
+                 collect_stats=False, engine=abi.ENGINE_AUTO, want_stats=False, context=0):
     """rayca_hip_render_multi: one frame on len(scenes) devices of this process, scenes[i] = the DeviceScene that renders
     part i (created on its own device); returns (rgba8 (H, W, 4), [stats per device] | None)."""
     l = scenes[0]._lib
-    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
-    o = abi.RaycaMultiOptions()
-    o.traversal, o.collect_stats, o.band_rows, o.gather, o.engine = traversal, int(collect_stats), band_rows, gather, engine
+    handles, o, cfg = _multi_args(scenes, config, band_rows, gather, traversal, collect_stats, engine, context)
     u8 = np.zeros((height, width, 4), np.uint8)
     st = (abi.RaycaStats * len(scenes))() if (want_stats or collect_stats) else None
-    cfg = config.to_abi()
     lib.check(l.rayca_hip_render_multi(handles, len(scenes), C.byref(cfg), width, height, C.byref(o), u8.ctypes.data, st))
     return u8, ([x.as_dict() for x in st] if st is not None else None)
+
+
+class MultiFrames:
+    """Frames in flight through the several-devices entry (rayca_hip_render_multi_issue / _wait): `issue(context, out)`
+    queues a whole frame -- every part's kernels, the one exchange, de-interleave, copy into `out` -- on frame context
+    `context` of every scene and returns; `wait(context)` blocks until that frame has landed.  A host that walks the
+    contexts in turn keeps that many frames in flight on every device (what a C or Rust host of the library does)."""
+
+    def __init__(self, scenes, config: Config, width: int, height: int, *, band_rows=8, gather=abi.GATHER_RCCL,
+                 traversal=abi.TRAVERSAL_ORDERED, engine=abi.ENGINE_AUTO):
+        self.scenes, self.width, self.height = list(scenes), width, height
+        self._l = scenes[0]._lib
+        self._args = {}
+        self._mk = lambda ctx: _multi_args(self.scenes, config, band_rows, gather, traversal, False, engine, ctx)
+
+    def issue(self, context: int, out) -> None:
+        """out: a (H, W, 4) uint8 numpy array (kept alive by the caller until wait) or a device pointer (int)."""
+        if context not in self._args:
+            self._args[context] = self._mk(context)
+        handles, o, cfg = self._args[context]
+        on_device = isinstance(out, int)
+        o.output_on_device = int(on_device)
+        ptr = out if on_device else out.ctypes.data
+        lib.check(self._l.rayca_hip_render_multi_issue(handles, len(self.scenes), C.byref(cfg), self.width, self.height, C.byref(o), ptr))
+
+    def wait(self, context: int) -> None:
+        handles = self._args[context][0] if context in self._args else (C.c_void_p * len(self.scenes))(*[s.handle for s in self.scenes])
+        lib.check(self._l.rayca_hip_render_multi_wait(handles, len(self.scenes), context))
 
 
 class SoftRenderer:

@@ -63,3 +63,62 @@ def test_bench_relaunches_itself_before_importing_torch():
     body = src[src.index("def main():"):]
     assert body.index("relaunch_self(args.gpus)") < body.index("import torch")
     assert '"WORLD_SIZE" not in os.environ' in body
+
+
+SLEEPER = textwrap.dedent("""
+    import os, sys, time
+    open(sys.argv[1] + "." + os.environ["RANK"], "w").write(str(os.getpid()))
+    time.sleep(600)
+""")
+
+
+def _pids_gone(pids, within_s=15.0):
+    import time
+    t_end = time.monotonic() + within_s
+    while time.monotonic() < t_end:
+        live = []
+        for pid in pids:
+            try:
+                os.kill(pid, 0)
+                # (a zombie of our own driver's child has been reaped by the driver; anything still signalable is alive)
+                live.append(pid)
+            except ProcessLookupError:
+                pass
+        if not live:
+            return True
+        time.sleep(0.1)
+    return False
+
+
+def _start_sleepers(tmp_path, world=2):
+    import time
+    prog = tmp_path / "sleeper.py"
+    prog.write_text(SLEEPER)
+    drv = tmp_path / "driver.py"
+    drv.write_text(DRIVER.format(root=ROOT))
+    stamp = str(tmp_path / "pid")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    parent = subprocess.Popen([sys.executable, str(drv), str(world), str(prog), stamp], env=env)
+    t_end = time.monotonic() + 60
+    while time.monotonic() < t_end and not all(os.path.exists(f"{stamp}.{r}") and open(f"{stamp}.{r}").read() for r in range(world)):
+        time.sleep(0.05)
+    pids = [int(open(f"{stamp}.{r}").read()) for r in range(world)]
+    return parent, pids
+
+
+def test_ranks_do_not_outlive_a_terminated_launcher(tmp_path):
+    """SIGTERM to the launching process (a harness `timeout`): its handler raises into the try/finally that stops the
+    exact child PIDs; exit code 128 + SIGTERM."""
+    import signal
+    parent, pids = _start_sleepers(tmp_path)
+    parent.send_signal(signal.SIGTERM)
+    assert parent.wait(timeout=30) == 128 + signal.SIGTERM
+    assert _pids_gone(pids)
+
+
+def test_ranks_do_not_outlive_a_killed_launcher(tmp_path):
+    """SIGKILL leaves the launcher no chance to clean up: the ranks go through the parent-death signal."""
+    parent, pids = _start_sleepers(tmp_path)
+    parent.kill()
+    parent.wait(timeout=30)
+    assert _pids_gone(pids)
