@@ -75,6 +75,11 @@ __global__ __launch_bounds__(kBlock) void k_valu(float* out, uint32_t iters, flo
         if (OP == 16) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
         if (OP == 17) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(acc[i]));
         if (OP == 18) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+        if (OP == 21) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(a));
+        if (OP == 22) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(acc[i]) : "v"(a), "v"(b));
+        if (OP == 23) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(a) : "vcc");   // two VALU instructions
+        if (OP == 24) asm volatile("v_cmp_lt_f32_e64 %2, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "s"(mask));   // two VALU instructions
+        if (OP == 25) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(a) : "vcc");   // two VALU instructions
         if (OP == 19) {   // the slab test's own mix: 6 fma, 3 max, 3 min, min3, max3, 2 cmp -- per 16: 6 fma + 10 others
           if (i < 6) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
           else if (i < 9) asm volatile("v_max_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
@@ -174,14 +179,16 @@ int main(int argc, char** argv) {
   const size_t lds_cu = 160u * 1024u;
 
   if (what == "all" || what == "valu") {
-    constexpr int kOps = 21;
+    constexpr int kOps = 26;
     const char* names[kOps] = {"v_fma_f32", "v_max_f32", "v_max3_f32", "v_pk_fma_f32", "v_cndmask_b32 (vcc)", "v_fma_mix_f32", "v_min_f32/v_max_f32",
                                "v_add_f32", "v_mul_f32", "v_cndmask_b32_e64 (sgpr pair)", "v_cmp_lt_f32 (vcc)", "v_cmp_lt_f32_e64 (sgpr pair)", "v_mov_b32",
                                "v_and_b32", "v_add_u32", "v_lshlrev_b32", "v_med3_f32", "v_cvt_f32_ubyte1", "v_sub_f32",
-                               "slab mix: 6 fma + 3 max + 3 min + min3 + max3 + 2 cmp", "centre/half mix: 12 fma + min3 + max3 + 2 cmp"};
+                               "slab mix: 6 fma + 3 max + 3 min + min3 + max3 + 2 cmp", "centre/half mix: 12 fma + min3 + max3 + 2 cmp",
+                               "v_cndmask_b32_e64 (vcc)", "v_cndmask_b32_e32 (vcc), dst != src", "pair: v_cmp_e32 vcc + v_cndmask_e32 vcc", "pair: v_cmp_e64 sgpr + v_cndmask_e64 sgpr",
+                               "pair: v_cmp_e32 vcc + v_cndmask_e64 vcc"};
     using K = void (*)(float*, uint32_t, float, float);
     K kernels[kOps] = {k_valu<0>, k_valu<1>, k_valu<2>, k_valu<3>, k_valu<4>, k_valu<5>, k_valu<6>, k_valu<7>, k_valu<8>, k_valu<9>, k_valu<10>,
-                       k_valu<11>, k_valu<12>, k_valu<13>, k_valu<14>, k_valu<15>, k_valu<16>, k_valu<17>, k_valu<18>, k_valu<19>, k_valu<20>};
+                       k_valu<11>, k_valu<12>, k_valu<13>, k_valu<14>, k_valu<15>, k_valu<16>, k_valu<17>, k_valu<18>, k_valu<19>, k_valu<20>, k_valu<21>, k_valu<22>, k_valu<23>, k_valu<24>, k_valu<25>};
     const uint32_t iters = 2000;
     for (int op = 0; op < kOps; ++op) {
       for (int w : {1, 2, 4, 8}) {   // waves per SIMD = blocks per CU
@@ -189,7 +196,7 @@ int main(int argc, char** argv) {
         CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[op]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu));
         const int grid = cus * w;
         const double ms = time_launch([&] { hipLaunchKernelGGL(kernels[op], dim3(grid), dim3(kBlock), lds, nullptr, out, iters, 1.0001f, 0.5f); });
-        const double wave_instr = (double)grid * 4.0 * iters * 4.0 * kIlp;
+        const double wave_instr = (double)grid * 4.0 * iters * 4.0 * kIlp * (op >= 23 && op <= 25 ? 2.0 : 1.0);
         const double rate = wave_instr / (ms * 1e-3);
         const double cyc = (double)cus * 4.0 * clock_ghz * 1e9 / rate;   // SIMD cycles per wave-instruction at the maximum clock
         printf("{\"bench\": \"valu\", \"op\": \"%s\", \"waves_per_simd\": %d, \"grid\": %d, \"ms\": %.4f, \"G_wave_instr_per_s\": %.2f, "

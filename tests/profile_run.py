@@ -1,15 +1,19 @@
-"""Workload for rocprofv3 passes: the bench configuration (atrium 1080p, primary + 1 shadow), a few frames.
-usage: python3 tests/profile_run.py [atrium|soup] [pt1|flat] [frames]"""
+"""Workload for rocprofv3 --pmc passes: a few frames of one bench workload, one frame at a time (the same launches
+bench.py's roofline loop times).  usage: python3 tests/profile_run.py [atrium|soup|cornell|atrium4k] [frames]
+The node format (and the soup's camera-ray kernel) is pinned by the caller through RAYCA_NODE_FORMAT / RAYCA_REFILL to what
+the un-profiled bench settles on: counter collection perturbs the scene's own timing of the formats."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from rayca_amd import Config, DeviceScene, IntegratorStrategy, flatten, scenes, abi
+import bench
+from rayca_amd import DeviceScene, flatten, scenes, abi
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"
-mode = sys.argv[2] if len(sys.argv) > 2 else "pt1"
-frames = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-desc, W, H = (flatten(scenes.atrium_scene()), 1920, 1080) if wl == "atrium" else (flatten(scenes.soup_scene()), 4096, 4096)
-cfg = Config(max_depth=1) if mode == "pt1" else Config(integrator=IntegratorStrategy.Flat)
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+w = bench.workload_config(wl)
+cfg, W, H = w["cfg"], w["width"], w["height"]
+desc = flatten(scenes.WORKLOADS["atrium" if wl == "atrium4k" else wl]["scene"]())
 ds = DeviceScene(desc, cfg, builder=abi.BUILDER_SAH)
+ds.finish()
 for _ in range(frames):
     st = ds.render(cfg, W, H, want_f32=False)[2]
-print(wl, mode, st["kernel_ms"], st["trace_kernel_ms"])
+print(wl, st["kernel_ms"], st["trace_kernel_ms"], "node_format", st["node_format"], dict(zip(abi.KERNEL_NAMES, zip(st["class_launches"], st["class_ms"]))))
