@@ -180,19 +180,25 @@ __global__ __launch_bounds__(kBlock, MODE == kModeFlat ? RAYCA_MIN_WAVES_FLAT : 
       QueuedRay next{};
       if (tail) {
         // all direct samples done: Pathtracer::trace_impl tail  pathtracer.rs:89-105
+        const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
+        const bool hemi = fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE;
+        F4 sdir = vec3(0.0f, 0.0f, 0.0f);
+        if (depth < limit) {
+          // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40.  The direction in the
+          // sampler's own frame only needs the two random numbers: made before the parked context comes back from LDS, so that
+          // the double-precision temporaries of libm_exact.hpp (the host libm's bits) and the context are not live together
+          const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
+          const float theta = hemi ? rc_acosf(e1) : rc_acosf(sqrtf(e1));
+          const float omega_a = 2.0f * kPi * e2;
+          const float st = rc_sinf(theta);
+          sdir = vec3(rc_cosf(omega_a) * st, rc_sinf(omega_a) * st, rc_cosf(theta));
+        }
         if (PARK) {
           cx = unpark_ctx(ctx_slot);
           direct = as_color(ctx_slot[6 * kBlock]);
         }
-        const uint32_t limit = fp.direct_sampler != RAYCA_SAMPLER_NONE ? fp.max_depth - 1u : fp.max_depth;
         pb.direct[slot] = as_f4(direct);
         if (depth < limit) {
-          // CosineSampler::get_random_dir  sampler/cosine.rs:65-88 ; HemisphereSampler  hemisphere.rs:17-40
-          const float e1 = rng_f32(key, dim++), e2 = rng_f32(key, dim++);
-          const bool hemi = fp.indirect_sampler == RAYCA_SAMPLER_HEMISPHERE;
-          const float theta = hemi ? acosf(e1) : acosf(sqrtf(e1));
-          const float omega_a = 2.0f * kPi * e2;
-          const F4 sdir = vec3(cosf(omega_a) * sinf(theta), sinf(omega_a) * sinf(theta), cosf(theta));
           const F4 w = cx.normal;
           const F4 a = close(w, vec3(0, 1, 0)) ? vec3(1, 0, 0) : vec3(0, 1, 0);
           const F4 u = normalized(cross(a, w));

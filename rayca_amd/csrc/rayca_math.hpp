@@ -18,6 +18,8 @@
 #include <cmath>
 #include <cstdint>
 
+#include "libm_exact.hpp"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define RC_FN __host__ __device__ __forceinline__
