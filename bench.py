@@ -94,7 +94,7 @@ def parse_args(argv=None):
     ap.add_argument("--builder", default="sah", choices=["sah", "reference"],
                     help="sah: SAH tree with empty-seeded candidate boxes (default); reference: the reference's tree, quirks included")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames rendered concurrently (frame contexts + streams); 0 = 4, the number of HIP hardware queues")
+                    help="frames rendered concurrently (frame contexts + streams); 0 = 4 on one GPU (the number of HIP hardware queues), 3 per rank with N > 1 (the fourth queue is the gather's)")
     ap.add_argument("--gather-batch", type=int, default=4,
                     help="N > 1: frames per collective of the SECOND timed run (the first, `value`, always gathers every frame on its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,7 +201,11 @@ def run_workload(env, args, name, steps, warmup, main):
     # 0.071 / 0.071 -- four, the number of HIP hardware queues (eight queues, GPU_MAX_HW_QUEUES=8, change nothing)
     is_path = int(getattr(cfg, "integrator", 5)) == 5
     wl_generations = int(getattr(cfg, "max_depth", 1)) if is_path else 1
-    F = args.frames_in_flight if args.frames_in_flight > 0 else 4
+    # N > 1: three frame streams, so that the comm stream has the fourth hardware queue to itself -- with four frame streams the
+    # gather shares a queue with one of them and a rank's half / quarter / eighth of the 1080p frame takes 0.250 / 0.145 /
+    # 0.100 ms per frame with the per-frame gather instead of 0.212 / 0.131 / 0.097 (tests/gpu_rank_share_probe.py,
+    # profiles/r03_rank_share.log; without a gather four are better: 0.197 / 0.106 / 0.063 against 0.208 / 0.126 / 0.086)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (4 if world == 1 else 3)
     F = max(1, min(F, 8))
     outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
     out = outs[0]

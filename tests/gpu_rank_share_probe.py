@@ -50,10 +50,66 @@ for parts in parts_list:
                                        wait_event=evg[i].cuda_event, record_event=ev[i].cuda_event) for i in range(F)]
         else:
             issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i) for i in range(F)]
+        comm_thread = os.environ.get("RAYCA_PROBE_COMM_THREAD", "0") == "1"
+        if comm_thread:   # the collectives issued by a thread of their own: the frame loop only hands it frame indices
+            import queue, threading
+            jobs = queue.SimpleQueue()
+
+            def comm_loop():
+                torch.cuda.set_device(0)
+                while True:
+                    i = jobs.get()
+                    if i is None:
+                        return
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(ev[i])
+                        dist.gather(sends[i], recv, dst=0)
+                        evg[i].record(comm)
+            th = threading.Thread(target=comm_loop, daemon=True)
+            th.start()
+            # (a frame's wait_event must see the gather's record: the thread records evg[i] some time after the frame loop has
+            # moved on -- with F buffers in turn the loop comes back to buffer i F frames later; guarded by a host-side count)
+            done = [threading.Semaphore(0) for _ in range(F)]
         for gather in (False, True):
             host = 0.0
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            if comm_thread and gather:
+                pending = [0] * F
+
+                def comm_loop2():
+                    torch.cuda.set_device(0)
+                    while True:
+                        i = jobs.get()
+                        if i is None:
+                            return
+                        with torch.cuda.stream(comm):
+                            comm.wait_event(ev[i])
+                            dist.gather(sends[i], recv, dst=0)
+                            evg[i].record(comm)
+                        done[i].release()
+                jobs.put(None)
+                th.join()
+                th = threading.Thread(target=comm_loop2, daemon=True)
+                th.start()
+                for k in range(K):
+                    i = k % F
+                    h0 = time.perf_counter()
+                    if pending[i]:
+                        done[i].acquire()      # the gather out of this buffer has been ISSUED (its event recorded): the frame may wait on it
+                        pending[i] = 0
+                    issue[i]()
+                    jobs.put(i)
+                    pending[i] = 1
+                    host += time.perf_counter() - h0
+                for i in range(F):
+                    if pending[i]:
+                        done[i].acquire()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / K * 1e3
+                scale = f"x{whole_ms / ms:.2f} of one GPU's" if whole_ms else ""
+                print(f"{wl} parts {parts} ({rows} rows) F={F} comm thread     gather=per frame: {ms:.4f} ms/frame, host (frame loop) {host / K * 1e6:.1f} us/frame  -> {parts}-GPU frame rate {scale}", flush=True)
+                continue
             for k in range(K):
                 i = k % F
                 h0 = time.perf_counter()
@@ -75,4 +131,6 @@ for parts in parts_list:
                 whole_ms = ms   # one GPU's own frame time, measured here: what the shares are compared with
             scale = f"x{whole_ms / ms:.2f} of one GPU's" if whole_ms else "(run with parts 1 first for the ratio)"
             print(f"{wl} parts {parts} ({rows} rows) F={F} calls/frame={'1' if single_call else '3'} gather={'per frame' if gather else 'none':9s}: {ms:.4f} ms/frame, host {host / K * 1e6:.1f} us/frame  -> {parts}-GPU frame rate {scale}", flush=True)
+if os.environ.get("RAYCA_PROBE_COMM_THREAD", "0") == "1":
+    jobs.put(None)
 dist.destroy_process_group()

@@ -1,9 +1,12 @@
 """Outlier accounting of the shaded-frame parity tests.
 
-Bit-exactness holds for hit records and Flat frames.  Frames that go through transcendental functions (acos/sin/cos of
-the bounce samplers, powf of the Phong lobe) can differ from the oracle in a handful of pixels: a last-bit difference
-in a bounce direction lets one path leave a silhouette on the other side.  Every such test states its MEASURED number of
-pixels beyond tolerance (tests/parity_bounds.json, copied from a run on MI355X) and fails when the count grows; the
+Bit-exactness holds for hit records and Flat frames.  Shaded frames are compared at 1e-4 per channel.  Round 2 still had
+three cases with pixels beyond it (39 of 15 360 on the 4K 4-bounce rows, 2 on Cornell depth 5): the bounce samplers'
+acosf / sinf / cosf came from the device's libm, which differs from the host's in the last bit on 12-33 % of the arguments, and
+a direction that differs in its last bit lets a path leave a silhouette on the other side.  Since round 3 the kernels
+evaluate those three with the host libm's own algorithms (rayca_amd/csrc/libm_exact.hpp, bit-identical on every sampler
+argument) and EVERY case is at zero (profiles/r03_parity_outliers.json; worst error of any case 3.0e-5, of the path-traced
+ones 6.6e-7): tests/parity_bounds.json is empty, and a case without an entry must have no pixel beyond tolerance.  The
 counts of the current run are written to gpurun_out/parity_outliers.json."""
 import json
 import os
