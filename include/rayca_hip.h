@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define RAYCA_ABI_VERSION 2u   /* 2: RaycaRenderOptions.wait_event / record_event, RaycaStats.class_ms / class_launches,
-                                  RaycaMultiOptions.context, rayca_hip_render_multi_issue / _wait */
+                                  RaycaMultiOptions.context, rayca_hip_render_multi_issue / _wait, rayca_hip_scene_reap */
 #define RAYCA_NONE 0xFFFFFFFFu /* Handle::NONE, rayca-util/src/pack.rs:61-64 */
 
 /* ---- status codes -------------------------------------------------------------------------- */
@@ -418,7 +418,15 @@ void rayca_hip_config_default(RaycaConfig* out);
  * reused for any number of render calls. `cfg` may be NULL (defaults); only cfg->bvh is read. */
 int32_t rayca_hip_scene_create(const RaycaSceneDesc* desc, const RaycaConfig* cfg,
                                const RaycaBuildOptions* opts, RaycaScene** out);
+/* Drop of the BvhScene / Tlas at the end of draw() (scene.rs:154).  Returns at once: the scene's last frames are waited for and
+ * its device memory, streams and host arrays released by a thread of the library (7-27 ms of hipFree / hipStreamDestroy that
+ * a host rebuilding the scene for every frame would otherwise pay per frame).  The handle is invalid from the call on.
+ * Pending releases are completed before the next rayca_hip_scene_create allocates, by rayca_hip_scene_reap, and when the
+ * library is unloaded. */
 int32_t rayca_hip_scene_destroy(RaycaScene* scene);
+/* Waits until every scene handed to rayca_hip_scene_destroy so far has been released (a host that wants the device memory
+ * back at a known point).  No reference counterpart. */
+int32_t rayca_hip_scene_reap(void);
 int32_t rayca_hip_scene_info(const RaycaScene* scene, RaycaSceneInfo* out);
 /* rayca_hip_scene_create returns as soon as frames can be rendered -- on the binary f32 nodes; the 4-wide and fp16
  * node formats a RAYCA_BUILDER_SAH scene times against them are encoded and uploaded by a thread of their own, and

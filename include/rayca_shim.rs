@@ -315,6 +315,7 @@ extern "C" {
     pub fn rayca_hip_config_default(out: *mut RaycaConfig);
     pub fn rayca_hip_scene_create(desc: *const RaycaSceneDesc, cfg: *const RaycaConfig, opts: *const RaycaBuildOptions, out: *mut *mut RaycaScene) -> i32;
     pub fn rayca_hip_scene_destroy(scene: *mut RaycaScene) -> i32;
+    pub fn rayca_hip_scene_reap() -> i32;
     pub fn rayca_hip_scene_info(scene: *const RaycaScene, out: *mut RaycaSceneInfo) -> i32;
     pub fn rayca_hip_scene_finish(scene: *mut RaycaScene) -> i32;
     pub fn rayca_hip_render(scene: *mut RaycaScene, cfg: *const RaycaConfig, width: u32, height: u32, opts: *const RaycaRenderOptions, rgba8_out: *mut u8, rgba32f_out: *mut f32, stats_out: *mut RaycaStats) -> i32;

@@ -354,6 +354,8 @@ def bind_product_signatures(lib):
     lib.rayca_hip_scene_create.argtypes = [P(RaycaSceneDesc), P(RaycaConfig), P(RaycaBuildOptions), P(C.c_void_p)]
     lib.rayca_hip_scene_destroy.restype = C.c_int32
     lib.rayca_hip_scene_destroy.argtypes = [C.c_void_p]
+    lib.rayca_hip_scene_reap.restype = C.c_int32
+    lib.rayca_hip_scene_reap.argtypes = []
     lib.rayca_hip_scene_info.restype = C.c_int32
     lib.rayca_hip_scene_info.argtypes = [C.c_void_p, P(RaycaSceneInfo)]
     lib.rayca_hip_scene_finish.restype = C.c_int32
@@ -385,7 +387,7 @@ def bind_product_signatures(lib):
 
 PRODUCT_SYMBOLS = [
     "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_selftest", "rayca_hip_last_error", "rayca_hip_config_default",
-    "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_info", "rayca_hip_scene_finish", "rayca_hip_render",
+    "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_reap", "rayca_hip_scene_info", "rayca_hip_scene_finish", "rayca_hip_render",
     "rayca_hip_render_device", "rayca_hip_tile_rows", "rayca_hip_trace_rays",
     "rayca_hip_scene_primitive_order", "rayca_hip_render_multi", "rayca_hip_render_multi_issue", "rayca_hip_render_multi_wait",
     "rayca_hip_rccl_status",

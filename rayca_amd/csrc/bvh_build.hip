@@ -156,7 +156,11 @@ __device__ __forceinline__ void bin_range(const BuildState& st, const DNode& nd,
 }
 
 // bins of the big nodes: one workgroup per kChunk positions, merged into the node's global bins
-__global__ __launch_bounds__(kB) void k_bin_init(BuildState st, uint32_t slots) {
+// The level kernels are launched with grids that BOUND the level's work -- the host does not wait for the previous level
+// to learn the exact counts -- and take the counts themselves from `lc`, the record of their level: {open nodes, chunks of
+// big nodes, big slots}, written by the level before (k_build_level's atomics on the next record; zeroed once per build).
+__global__ __launch_bounds__(kB) void k_bin_init(BuildState st, const uint32_t* lc) {
+  const uint32_t slots = lc[2];
   const uint32_t i = blockIdx.x * kB + threadIdx.x;
   if (i >= slots * 3 * 64) return;
   uint32_t* g = st.gbins + (size_t)i * 7;
@@ -166,10 +170,11 @@ __global__ __launch_bounds__(kB) void k_bin_init(BuildState st, uint32_t slots) 
     g[4 + c] = enc(-FLT_MAX);
   }
 }
-__global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chunks) {
+__global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chunks, const uint32_t* lc) {
   __shared__ uint32_t s_cnt[3][64];
   __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
   __shared__ float s_pos[3][64];
+  if (blockIdx.x >= lc[1]) return;   // (block-uniform: before any barrier)
   const uint2 job = chunks[blockIdx.x];
   const DNode nd = st.nodes[job.x];
   init_bins(nd, s_cnt, s_min, s_max, s_pos);
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chun
   }
 }
 
-__global__ __launch_bounds__(kBuildLevelMaxBlock) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level) {
+__global__ __launch_bounds__(kBuildLevelMaxBlock) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level,
+                                                                  const uint32_t* lc) {
+  if (blockIdx.x >= lc[0]) return;   // (block-uniform: before any barrier)
   __shared__ uint32_t s_cnt[3][64];
   __shared__ uint32_t s_min[3][64][3], s_max[3][64][3];
   __shared__ float s_pos[3][64];
@@ -770,7 +777,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   size_t off_f[9], off_u[9];
   for (int i = 0; i < 9; ++i) off_f[i] = reserve(sizeof(float) * n);
   for (int i = 0; i < 9; ++i) off_u[i] = reserve(sizeof(uint32_t) * ((size_t)n + 2));
-  const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_big = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
+  const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_big = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_levels = reserve(sizeof(uint32_t) * 4u * ((size_t)in.max_depth + 2u)), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
   const size_t off_chunks[2] = {reserve((size_t)max_chunks * sizeof(uint2)), reserve((size_t)max_chunks * sizeof(uint2))};
   size_t off_layout[8] = {};
   if (keep)
@@ -801,8 +808,8 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   st.slot_count = st.node_count + 4;
   st.gbins = reinterpret_cast<uint32_t*>(base + off_gbins);
   for (int i = 0; i < 2; ++i) st.chunks[i] = reinterpret_cast<uint2*>(base + off_chunks[i]);
-  uint32_t* next_count = st.node_count + 1;
   st.small_count = st.node_count + 2;
+  uint32_t* const level_counts = reinterpret_cast<uint32_t*>(base + off_levels);   // [level][open nodes, chunks, big slots, -]
   st.seed_origin = in.seed_origin ? 1u : 0u;
   st.max_depth = in.max_depth;
 
@@ -823,50 +830,67 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   HB_TRY(hipMemcpyAsync(st.node_count, init, sizeof init, hipMemcpyHostToDevice, stream));
   const uint32_t zero = 0;
   HB_TRY(hipMemcpyAsync(lists[0], &zero, 4, hipMemcpyHostToDevice, stream));  // level 0: the root
+  // the level records: all zero but the root's {one open node, its chunks, one big slot}
+  HB_TRY(hipMemsetAsync(level_counts, 0, sizeof(uint32_t) * 4u * ((size_t)in.max_depth + 2u), stream));
+  const uint32_t root_chunks = n > kBig ? (n + kChunk - 1) / kChunk : 0u;
+  const uint32_t record0[4] = {n > 0 ? 1u : 0u, root_chunks, n > kBig ? 1u : 0u, 0u};
+  HB_TRY(hipMemcpyAsync(level_counts, record0, sizeof record0, hipMemcpyHostToDevice, stream));
+  std::vector<uint2> rc(root_chunks);
+  for (uint32_t k = 0; k < root_chunks; ++k) rc[k] = make_uint2(0u, k);
+  if (root_chunks) HB_TRY(hipMemcpyAsync(st.chunks[0], rc.data(), sizeof(uint2) * root_chunks, hipMemcpyHostToDevice, stream));
   HB_TRY(hipStreamSynchronize(stream));  // (the sources above are locals and caller memory: staged before they go away)
   staged.finish();
 
   lap("alloc + upload");
-  uint32_t n_active = n > 0 ? 1u : 0u;
-  uint32_t n_chunks = 0, n_slots = 0;
-  if (n > kBig) {  // the root's chunks
-    n_slots = 1;
-    n_chunks = (n + kChunk - 1) / kChunk;
-    std::vector<uint2> rc(n_chunks);
-    for (uint32_t k = 0; k < n_chunks; ++k) rc[k] = make_uint2(0u, k);
-    HB_TRY(hipMemcpyAsync(st.chunks[0], rc.data(), sizeof(uint2) * n_chunks, hipMemcpyHostToDevice, stream));
-    HB_TRY(hipStreamSynchronize(stream));
-  }
+  // Levels: every level's record {open nodes, chunks, big slots} lives on the device (level_counts, zeroed once); the
+  // kernels of level L read record L for their bounds and count into record L + 1.  The host queues kLevelBatch levels at
+  // a time with grids that bound the work (an open node holds more than kSeq primitives, a level has at most 2^L nodes)
+  // and reads the records back once per batch -- round 2 read three counters back after EVERY level: 19 stream
+  // synchronisations for the atrium, a third of the build.
+  constexpr uint32_t kLevelBatch = 8;
   uint32_t levels_run = 0, blocks_run = 0;
-  for (uint32_t level = 0; level < in.max_depth && n_active > 0; ++level) {
-    ++levels_run;
-    blocks_run += n_active;
+  uint32_t n_active = n > 0 ? 1u : 0u;
+  bool big_possible = n > kBig;   // (a big node only has big ancestors: once a level has none, no later level has)
+  std::vector<uint32_t> lc_host;
+  for (uint32_t level0 = 0; level0 < in.max_depth && n_active > 0; level0 += kLevelBatch) {
+    const uint32_t batch = std::min<uint32_t>(kLevelBatch, in.max_depth - level0);
     const auto lt0 = std::chrono::steady_clock::now();
-    const uint32_t blocks_this_level = n_active;
-    if (n_chunks) {  // big nodes of this level: bins by many workgroups
-      hipLaunchKernelGGL(k_bin_init, dim3((n_slots * 3 * 64 + kB - 1) / kB), dim3(kB), 0, stream, st, n_slots);
-      hipLaunchKernelGGL(k_bin_big, dim3(n_chunks), dim3(kB), 0, stream, st, st.chunks[level & 1]);
+    for (uint32_t level = level0; level < level0 + batch; ++level) {
+      const uint32_t* lc = level_counts + 4u * level;
+      uint32_t* lc_next = level_counts + 4u * (level + 1u);
+      const uint64_t by_depth = level < 31u ? (1ull << level) : ~0ull;
+      const uint32_t bound = (uint32_t)std::min<uint64_t>(by_depth, (uint64_t)n / (kSeq + 1u) + 1u);
+      BuildState sl = st;
+      sl.chunk_count = lc_next + 1;
+      sl.slot_count = lc_next + 2;
+      if (big_possible) {  // big nodes of this level: bins by many workgroups
+        hipLaunchKernelGGL(k_bin_init, dim3((std::min<uint64_t>(by_depth, max_slots) * 3 * 64 + kB - 1) / kB), dim3(kB), 0, stream, sl, lc);
+        hipLaunchKernelGGL(k_bin_big, dim3((uint32_t)std::min<uint64_t>(by_depth * ((n + kChunk - 1) / kChunk), max_chunks)), dim3(kB), 0, stream, sl, sl.chunks[level & 1], lc);
+        HB_TRY(hipGetLastError());
+      }
+      hipLaunchKernelGGL(k_build_level, dim3(bound), dim3(big_possible ? kBuildLevelMaxBlock : kB), 0, stream, sl, lists[level & 1], lists[(level + 1) & 1], lc_next,
+                         sl.chunks[(level + 1) & 1], level, lc);
       HB_TRY(hipGetLastError());
     }
-    HB_TRY(hipMemsetAsync(next_count, 0, 4, stream));
-    HB_TRY(hipMemsetAsync(st.chunk_count, 0, 8, stream));  // chunk_count, slot_count
-    hipLaunchKernelGGL(k_build_level, dim3(n_active), dim3(n_chunks ? kBuildLevelMaxBlock : kB), 0, stream, st, lists[level & 1], lists[(level + 1) & 1], next_count,
-                       st.chunks[(level + 1) & 1], level);
-    HB_TRY(hipGetLastError());
-    uint32_t counters[5];
-    HB_TRY(hipMemcpyAsync(counters, st.node_count, sizeof counters, hipMemcpyDeviceToHost, stream));
+    lc_host.resize(4u * (batch + 1u));
+    HB_TRY(hipMemcpyAsync(lc_host.data(), level_counts + 4u * level0, sizeof(uint32_t) * lc_host.size(), hipMemcpyDeviceToHost, stream));
     HB_TRY(hipStreamSynchronize(stream));
-    n_active = counters[1];
-    n_chunks = counters[3];
-    n_slots = counters[4];
-    if (n_slots > max_slots || n_chunks > max_chunks) {
-      err = "gpu bvh build: big-node bookkeeping overflow";
-      cleanup();
-      return false;
+    for (uint32_t k = 0; k < batch; ++k) {
+      if (lc_host[4 * k] == 0) break;
+      ++levels_run;
+      blocks_run += lc_host[4 * k];
     }
+    for (uint32_t k = 1; k <= batch; ++k)
+      if (lc_host[4 * k + 2] > max_slots || lc_host[4 * k + 1] > max_chunks) {
+        err = "gpu bvh build: big-node bookkeeping overflow";
+        cleanup();
+        return false;
+      }
+    n_active = lc_host[4 * batch];
+    big_possible = big_possible && lc_host[4 * batch + 1] != 0;
     if (verbose && getenv("RAYCA_BUILD_LEVELS"))
-      fprintf(stderr, "[rayca build]     level %2u: %6u blocks %7.2f ms\n", level, blocks_this_level,
-              std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - lt0).count());
+      fprintf(stderr, "[rayca build]     levels %2u..%2u: %7.2f ms, %u open nodes left\n", level0, level0 + batch - 1,
+              std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - lt0).count(), n_active);
   }
   lap("levels");
   uint32_t n_small = 0;
