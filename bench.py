@@ -388,11 +388,33 @@ def run_workload(env, args, name, steps, warmup, main):
         host_ms = host_frame(pageable.ctypes.data)
         pinned = torch.empty((H, W, 4), dtype=torch.uint8, pin_memory=True)
         host_pinned_ms = host_frame(pinned.data_ptr())
+        # and the rate a host WITHOUT torch reaches with frames in flight behind the C ABI: rayca_hip_render_multi_issue / _wait
+        # (one device), four frame contexts in turn, every frame copied into page-locked host memory -- kernels + D2H per frame
+        from rayca_amd.renderer import MultiFrames
+        mf = MultiFrames([ds], cfg, W, H, band_rows=args.band_rows, gather=abi.GATHER_PEER_COPY)
+        hosts = [torch.empty((H, W, 4), dtype=torch.uint8, pin_memory=True) for _ in range(4)]
+        k_pipe = max(8, min(steps, 64))
+        for i in range(8):
+            if i >= 4:
+                mf.wait(i % 4)
+            mf.issue(i % 4, hosts[i % 4].data_ptr(), on_device=False)
+        for c in range(4):
+            mf.wait(c)
+        t2 = time.perf_counter()
+        for i in range(k_pipe):
+            if i >= 4:
+                mf.wait(i % 4)
+            mf.issue(i % 4, hosts[i % 4].data_ptr(), on_device=False)
+        for c in range(4):
+            mf.wait(c)
+        pipelined_host_ms = (time.perf_counter() - t2) / k_pipe * 1e3
         latency = {"frames_in_flight": 1,
                    "kernel_ms": round(frame_kernel_ms, 4),
                    "render_device_and_sync_ms": round(dev_sync_ms, 4),
                    "render_to_host_ms": round(host_ms, 4),
                    "render_to_pinned_host_ms": round(host_pinned_ms, 4),
+                   "pipelined_to_host_ms_per_frame": round(pipelined_host_ms, 4),
+                   "pipelined_to_host": "rayca_hip_render_multi_issue / _wait on one device, four frame contexts in turn, every frame copied into page-locked host memory: the frame rate a C or Rust host of the library gets, D2H included",
                    "frame_bytes_to_host": W * H * 4,
                    "note": "one frame at a time: HIP events around the frame's kernels; wall clock of rayca_hip_render_device + stream synchronise (frame stays in HBM); "
                            "wall clock of rayca_hip_render -- kernels + the copy into the caller's RGBA8 image, which is what the reference's own timer spans "

@@ -190,14 +190,16 @@ class MultiFrames:
         self._args = {}
         self._mk = lambda ctx: _multi_args(self.scenes, config, band_rows, gather, traversal, False, engine, ctx)
 
-    def issue(self, context: int, out) -> None:
-        """out: a (H, W, 4) uint8 numpy array (kept alive by the caller until wait) or a device pointer (int)."""
+    def issue(self, context: int, out, on_device=None) -> None:
+        """out: a (H, W, 4) uint8 numpy array (kept alive by the caller until wait), or a pointer (int): device memory of
+        scenes[0]'s device unless on_device=False (then host memory, e.g. a page-locked torch tensor's data_ptr)."""
         if context not in self._args:
             self._args[context] = self._mk(context)
         handles, o, cfg = self._args[context]
-        on_device = isinstance(out, int)
-        o.output_on_device = int(on_device)
-        ptr = out if on_device else out.ctypes.data
+        if on_device is None:
+            on_device = isinstance(out, int)
+        o.output_on_device = int(bool(on_device))
+        ptr = out if isinstance(out, int) else out.ctypes.data
         lib.check(self._l.rayca_hip_render_multi_issue(handles, len(self.scenes), C.byref(cfg), self.width, self.height, C.byref(o), ptr))
 
     def wait(self, context: int) -> None:

@@ -14,12 +14,13 @@ for set in "VmemLatency" "LdsLatency" "InstrFetchLatency" \
   echo "diag pass $i done"
 done
 python3 - "$tag" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, re
 tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(f"gpurun_out/diag_{tag}/pass*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
+        m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])   # ("void rayca::(anonymous namespace)::k_generation<...>(...)")
+        k = m.group(1) if m else r["Kernel_Name"][:30]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     if not k.startswith("k_"): continue
