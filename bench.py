@@ -440,8 +440,8 @@ def run_workload(env, args, name, steps, warmup, main):
     records = (16 + 16 + 4) * my_rows * W * max(wl_generations, 1) if is_path else 0   # direct colour, radiance factor, state per pixel and depth
     n_nodes, n_tris = int(info["node_count"]), int(info["triangle_count"])
     node_bytes = {0: 64 * n_nodes, 1: 128 * n_nodes // 3, 4: 32 * n_nodes, 5: 64 * n_nodes // 3}[node_format & 5]
-    compulsory_frame = node_bytes + (36 + 256 + 8) * n_tris + records + 4 * my_rows * W
-    compulsory = compulsory_frame if launches_per_frame == 1 else (node_bytes + 36 * n_tris + (records + 4 * my_rows * W) // max(launches_per_frame, 1))
+    compulsory_frame = node_bytes + (64 + 256 + 8) * n_tris + records + 4 * my_rows * W
+    compulsory = compulsory_frame if launches_per_frame == 1 else (node_bytes + 64 * n_tris + (records + 4 * my_rows * W) // max(launches_per_frame, 1))
     fmt = lambda w, h: ("4-wide" if w else "binary") + (" fp16" if h else " f32")   # noqa: E731
     result = {
         "metric": "Mrays/sec (primary+shadow), 1920x1080 Sponza 1spp" if name == "atrium" else f"Mrays/sec ({name})",

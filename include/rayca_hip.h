@@ -489,8 +489,8 @@ int32_t rayca_hip_render_multi(RaycaScene* const* scenes, uint32_t count, const 
  * issues frames with contexts 0, 1, 2, 3 in turn and waits for a context only before it re-uses it keeps four frames in
  * flight on every device -- the tail of one frame then runs under the head of the next, which is what a frame-at-a-time
  * loop leaves on the table (one GPU, 1080p primary + shadow: 0.51 -> 0.38 ms per frame; a rank's eighth 0.19 -> 0.06 ms).
- * rgba8_out (and host memory it points to) must stay valid until the matching wait.  Frames of one context are
- * serialised.  No statistics (they need a synchronisation per frame: use rayca_hip_render_multi).
+ * rgba8_out (and host memory it points to) must stay valid until the matching wait, and so must every scene handle: wait
+ * for the frames a scene takes part in before rayca_hip_scene_destroy.  Frames of one context are serialised.  No statistics (they need a synchronisation per frame: use rayca_hip_render_multi).
  * The drop-in host loop (draw.rs:7-9 called per frame) is `issue(ctx = f % 4)`, `wait(ctx = (f + 1) % 4)`. */
 int32_t rayca_hip_render_multi_issue(RaycaScene* const* scenes, uint32_t count, const RaycaConfig* cfg, uint32_t width,
                                      uint32_t height, const RaycaMultiOptions* opts, void* rgba8_out);

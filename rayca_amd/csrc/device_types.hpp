@@ -51,10 +51,11 @@ struct DevScene {
   const uint4* nodes_h;  // 2 x uint4 per DevNodeH, 4 x uint4 per DevNode4H: the same trees with fp16 boxes (or nullptr)
   const uint4* nodes4_h;
   float half_center[3], half_inv_scale;
-  const float* tris;    // 9 floats per primitive slot (world-space v0,v1,v2)
+  const float4* tris;   // 3 x float4 per primitive slot: world-space v0, v1, v2, tie rank, reference leaf (trace_core.inc TriRecord)
   const PrimExt* ext;   // per primitive slot
+  // the tables the primitive records' filter fields are filled from (k_fill_tri_filter); the kernels read the records
   const uint32_t* tie_rank;  // nullptr: ties go to the lower slot; else to the lower rank (RAYCA_BUILDER_SAH)
-  const uint32_t* ref_leaf_of;    // RAYCA_BUILDER_SAH: slot -> reference leaf (nullptr otherwise)
+  const uint32_t* ref_leaf_of;    // RAYCA_BUILDER_SAH: slot -> reference leaf (nullptr otherwise: no filter)
   const float4* ref_leaf_boxes;   // 2 x float4 per reference leaf: (min xyz, -), (max xyz, -)
   const DevMaterial* materials;
   const DevLight* lights;
@@ -65,7 +66,7 @@ struct DevScene {
   uint32_t root_ref, root_ref4;
   float root_min[3], root_max[3];
   float cull_abs;  // absolute slack of the best-t cull (see trace())
-  uint32_t tri_soa;  // 0: 36-B AoS triangles, 1: nine SoA planes of prim_count floats
+  uint32_t reserved;
 };
 
 // One launch renders `rows` packed rows of a width x height frame.
