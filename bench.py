@@ -118,7 +118,7 @@ def measured_peaks():
     return valu, l1, src
 
 
-def pmc_for(workload, builder, kernel, node_format_bits):
+def pmc_for(workload, builder, kernel, node_format_bits, record_bytes=64):
     """The committed per-launch counters of `kernel` on this workload -- only if they were collected on the same node
     format (generation kernels: the scene times the formats itself and may settle on another one than the profiled run).
     Returns (counters dict, launch_ms_under_pmc | None, source path) or (None, None, why)."""
@@ -139,6 +139,8 @@ def pmc_for(workload, builder, kernel, node_format_bits):
     want = k.get("node_format_bits")
     if want is not None and kernel in ("k_generation", "k_flat_refill") and int(want) != int(node_format_bits):
         return None, None, f"counters were collected on node format bits {want}, this run settled on {node_format_bits}"
+    if int(k.get("binary_f32_record_bytes", 64)) != int(record_bytes):   # (the binary f32 node record the library was built with)
+        return None, None, f"counters were collected on {k.get('binary_f32_record_bytes', 64)}-B binary f32 node records, this library reads {record_bytes}-B ones"
     return k["counters_per_launch"], k.get("launch_ms_under_pmc"), os.path.relpath(path, ROOT)
 
 
@@ -435,13 +437,14 @@ def run_workload(env, args, name, steps, warmup, main):
         return None
     mrays = rays_total * steps / elapsed_max / 1e6
     algo_rate = algo_bytes / (max(trace_frame_ms, 1e-9) * 1e-3) / 1e9
-    # what MUST cross the HBM interface once per frame: the scene's arrays in, path records and pixels out -- per launch of
+    # what MUST cross the HBM interface once per frame: the scene's arrays in (nodes, 48-B primitive records, shading
+    # records), path records and pixels out -- per launch of
     # the dominant kernel: its share of the frame's traversal launches
     records = (16 + 16 + 4) * my_rows * W * max(wl_generations, 1) if is_path else 0   # direct colour, radiance factor, state per pixel and depth
     n_nodes, n_tris = int(info["node_count"]), int(info["triangle_count"])
-    node_bytes = {0: 64 * n_nodes, 1: 128 * n_nodes // 3, 4: 32 * n_nodes, 5: 64 * n_nodes // 3}[node_format & 5]
-    compulsory_frame = node_bytes + (64 + 256 + 8) * n_tris + records + 4 * my_rows * W
-    compulsory = compulsory_frame if launches_per_frame == 1 else (node_bytes + 64 * n_tris + (records + 4 * my_rows * W) // max(launches_per_frame, 1))
+    node_bytes = {0: (48 if node_format & 4096 else 64) * n_nodes, 1: 128 * n_nodes // 3, 4: 32 * n_nodes, 5: 64 * n_nodes // 3}[node_format & 5]
+    compulsory_frame = node_bytes + (48 + 256 + 8) * n_tris + records + 4 * my_rows * W
+    compulsory = compulsory_frame if launches_per_frame == 1 else (node_bytes + 48 * n_tris + (records + 4 * my_rows * W) // max(launches_per_frame, 1))
     fmt = lambda w, h: ("4-wide" if w else "binary") + (" fp16" if h else " f32")   # noqa: E731
     result = {
         "metric": "Mrays/sec (primary+shadow), 1920x1080 Sponza 1spp" if name == "atrium" else f"Mrays/sec ({name})",
@@ -459,6 +462,7 @@ def run_workload(env, args, name, steps, warmup, main):
         "config": {"workload": wl["label"], "baseline_config": wl["baseline_config"], "width": W, "height": H, "triangles": info["triangle_count"],
                    "bvh_nodes": info["node_count"], "bvh_build_ms": round(info["build_ms"], 1), "hip_runtime_init_ms": round(info["runtime_init_ms"], 1), "bvh_built_on": "gpu (bvh_build.hip; same tree as the host builder)",
                    "node_format": {"generation0": fmt(node_format & 1, node_format & 4), "bounces": fmt(node_format & 2, node_format & 8),
+                                   "binary_f32_record": "48 B: centre + half extent, child references in the low halves of two half extents (3 loads)" if node_format & 4096 else "64 B: min / max planes + references (4 loads)",
                                    "camera_rays": "lane-refill kernel (refill.hip)" if node_format & 1024 else "generation kernel",
                                    "chosen_by": "timing the four formats, then the two camera-ray kernels, on this scene (same pixels with each)"},
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
@@ -481,7 +485,7 @@ def run_workload(env, args, name, steps, warmup, main):
                                               "Mrays_per_s": round(rays_total * steps / elapsed_batched_max / 1e6, 3),
                                               "note": "the same K frames, B finished frames per collective (fewer rendezvous); reported for comparison, not as `value`"}
     rl = result["roofline"]
-    counters, pmc_ms, src = pmc_for(name, args.builder, dom_name, node_format & 5) if world == 1 else (None, None, "counters describe the whole frame on one GPU")
+    counters, pmc_ms, src = pmc_for(name, args.builder, dom_name, node_format & 5, 48 if node_format & 4096 else 64) if world == 1 else (None, None, "counters describe the whole frame on one GPU")
     if counters:
         lim = roofline_limits(counters, dom_launch_ms, compulsory)
         rl.update(lim)

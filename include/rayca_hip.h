@@ -372,7 +372,10 @@ typedef struct RaycaStats {
    * the kernel that won), bit 10 = this frame's camera rays ran on
    * the lane-refill kernel, bit 11 = the scene's 4-wide / fp16 node formats were still being made when this frame was
    * issued (a thread started by rayca_hip_scene_create encodes and uploads them; until then frames traverse the binary
-   * f32 nodes and nothing is timed -- same pixels either way) */
+   * f32 nodes and nothing is timed -- same pixels either way), bit 12 = where "binary f32" nodes are traversed by the
+   * conservative (RAYCA_BUILDER_SAH) kernels they are read as 48-B centre / half-extent records (three 16-B loads per
+   * node instead of four; 0: 64-B min / max nodes).  Wavefront-engine frames report the formats their kernels are
+   * compiled for (bits 0-3). */
   uint32_t node_format;
   /* HIP-event time (ms, summed over the launches of the call) and number of launches per kernel class (RAYCA_KERNEL_*):
    * class_ms[k] / class_launches[k] is the live average launch duration of that kernel -- what bench.py prices its

@@ -47,6 +47,7 @@ struct DevLight {
 
 struct DevScene {
   const float4* nodes;  // 4 x float4 per DevNode (binary tree)
+  const float4* nodes_ch;  // RAYCA_BUILDER_SAH: the same nodes with every box as (centre xyz, half extent xyz): what the conservative binary f32 steps read (trace_core.inc slab_ch)
   const float4* nodes4; // 8 x float4 per DevNode4 (the same tree, 4-wide)
   const uint4* nodes_h;  // 2 x uint4 per DevNodeH, 4 x uint4 per DevNode4H: the same trees with fp16 boxes (or nullptr)
   const uint4* nodes4_h;

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_REFILL_WAVES) void k_flat_refill(DevS
 template <bool SPH, bool STATS>
 __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_queue_refill(DevScene sc, const QueuedRay* in_rays, const uint32_t* in_count, float4* hits,
                                                                               uint32_t* heads, TraceCounters* counters, TraceLaunch tl) {
-  constexpr bool WIDE = true, SPILL = true, HALF = true;
+  constexpr bool WIDE = RAYCA_WF_BOUNCE_WIDE != 0, SPILL = true, HALF = RAYCA_WF_BOUNCE_HALF != 0;   // (as k_wf_trace traverses bounce rays)
   extern __shared__ uint32_t lds_stack[];
   NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
   const uint32_t lane = __lane_id();
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_queue_refill(De
           stack.clear();
           float tmin;
           if (STATS) cnt.boxes++;
-          cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? sc.root_ref4 : kTerminated;
+          cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? (WIDE ? sc.root_ref4 : sc.root_ref) : kTerminated;
           has = true;
         }
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_queue_refill(De
 template <bool GEN0, bool SPH, bool STATS>
 __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_shadow_refill(DevScene sc, FrameParams fp, const QueuedRay* in_rays, const uint32_t* in_count, WfBuffers wb,
                                                                                 PathBuffers pb, uint32_t depth, uint32_t* heads, TraceCounters* counters, TraceLaunch tl) {
-  constexpr bool WIDE = true, SPILL = true, HALF = true;
+  constexpr bool WIDE = RAYCA_WF_SHADOW_WIDE != 0, SPILL = true, HALF = RAYCA_WF_SHADOW_HALF != 0;   // (as k_wf_shadow traverses them)
   extern __shared__ uint32_t lds_stack[];
   NodeStack<SPILL> stack = make_stack<SPILL>(lds_stack, tl, blockIdx.x * kBlock + threadIdx.x);
   const uint32_t lane = __lane_id();
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_shadow_refill(D
     stack.clear();
     float tmin;
     if (STATS) cnt.boxes++;
-    cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? sc.root_ref4 : kTerminated;
+    cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? (WIDE ? sc.root_ref4 : sc.root_ref) : kTerminated;
   };
   for (;;) {
     const uint32_t n_active = (uint32_t)__popcll(__ballot(cur != kTerminated));

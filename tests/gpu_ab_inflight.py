@@ -9,6 +9,7 @@ from rayca_amd import Config, DeviceScene, IntegratorStrategy, flatten, scenes, 
 wl, F, names = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
 vdir = os.path.join(ROOT, "rayca_amd", "csrc", "variants")
 if wl == "atrium": desc = flatten(scenes.atrium_scene()); W, H = 1920, 1080; cfgs = [("pt1", Config(max_depth=1)), ("flat", Config(integrator=IntegratorStrategy.Flat)), ("pt5", Config())]
+elif wl == "atrium4k": desc = flatten(scenes.atrium_scene()); W, H = 3840, 2160; cfgs = [("pt4", Config(max_depth=4))]
 else: desc = flatten(scenes.soup_scene()); W, H = 4096, 4096; cfgs = [("flat", Config(integrator=IntegratorStrategy.Flat))]
 dev = torch.device("cuda", 0)
 from rayca_amd.streams import frame_streams

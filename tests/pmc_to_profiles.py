@@ -36,6 +36,7 @@ for wl in wls:
         kernels[kname] = {
             "kernel_name": g.get("kernel_name"),
             "node_format_bits": PINNED.get(wl) if kname in ("k_generation", "k_flat_refill") else None,
+            "binary_f32_record_bytes": 48,   # (RaycaStats.node_format bit 12 of the library this session ran: RAYCA_NODE_CH48)
             "launch_ms_under_pmc": round(g["launch_ms_under_pmc"], 4), "dispatches_averaged": g["dispatches_averaged"],
             "hbm_traffic_bytes_per_launch": int((2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024),
             "l1_hit_rate": round(1.0 - g["TCP_TCC_READ_REQ_sum"] / max(g["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0), 4),
