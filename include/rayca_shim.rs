@@ -327,6 +327,7 @@ extern "C" {
     pub fn rayca_hip_tile_rows(tile: *const RaycaTile, height: u32) -> u32;
     pub fn rayca_hip_trace_rays(scene: *mut RaycaScene, opts: *const RaycaRenderOptions, count: u32, rays: *const f32, t_out: *mut f32, prim_out: *mut u32, uv_out: *mut f32, stats_out: *mut RaycaStats) -> i32;
     pub fn rayca_hip_scene_primitive_order(scene: *const RaycaScene, prim_order: *mut u32, capacity: u32) -> i32;
+    pub fn rayca_hip_scene_read_nodes(scene: *mut RaycaScene, which: u32, out: *mut c_void, capacity_bytes: u64, bytes_out: *mut u64) -> i32;
 }
 
 // ---- Config -------------------------------------------------------------------------------------------------------------

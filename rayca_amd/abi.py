@@ -373,6 +373,8 @@ def bind_product_signatures(lib):
                                          C.c_void_p, C.c_void_p, P(RaycaStats)]
     lib.rayca_hip_scene_primitive_order.restype = C.c_int32
     lib.rayca_hip_scene_primitive_order.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.rayca_hip_scene_read_nodes.restype = C.c_int32
+    lib.rayca_hip_scene_read_nodes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.rayca_hip_rccl_status.restype = C.c_int32
     lib.rayca_hip_rccl_status.argtypes = []
     lib.rayca_hip_render_multi.restype = C.c_int32
@@ -389,6 +391,6 @@ PRODUCT_SYMBOLS = [
     "rayca_hip_version", "rayca_hip_device_count", "rayca_hip_selftest", "rayca_hip_last_error", "rayca_hip_config_default",
     "rayca_hip_scene_create", "rayca_hip_scene_destroy", "rayca_hip_scene_reap", "rayca_hip_scene_info", "rayca_hip_scene_finish", "rayca_hip_render",
     "rayca_hip_render_device", "rayca_hip_tile_rows", "rayca_hip_trace_rays",
-    "rayca_hip_scene_primitive_order", "rayca_hip_render_multi", "rayca_hip_render_multi_issue", "rayca_hip_render_multi_wait",
+    "rayca_hip_scene_primitive_order", "rayca_hip_scene_read_nodes", "rayca_hip_render_multi", "rayca_hip_render_multi_issue", "rayca_hip_render_multi_wait",
     "rayca_hip_rccl_status",
 ]

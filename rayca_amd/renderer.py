@@ -82,6 +82,14 @@ class DeviceScene:
         lib.check(self._lib.rayca_hip_scene_primitive_order(self.handle, out.ctypes.data, n))
         return out
 
+    def read_nodes(self, which: int) -> np.ndarray:
+        """rayca_hip_scene_read_nodes: which = 0 the 64-B binary nodes as (N, 16) uint32, 1 the 48-B centre / half records as (N, 12)"""
+        n = C.c_uint64(0)
+        lib.check(self._lib.rayca_hip_scene_read_nodes(self.handle, which, None, 0, C.byref(n)))
+        out = np.zeros(n.value // 4, np.uint32)
+        lib.check(self._lib.rayca_hip_scene_read_nodes(self.handle, which, out.ctypes.data, n.value, None))
+        return out.reshape(-1, 16 if which == 0 else 12)
+
     @staticmethod
     def _opts(traversal, collect_stats, tile, stream, engine=abi.ENGINE_AUTO, context=0, camera_rays=abi.CAMERA_AUTO):
         o = abi.RaycaRenderOptions()
