@@ -526,8 +526,8 @@ int32_t rayca_hip_scene_primitive_order(const RaycaScene* scene, uint32_t* prim_
  * which = 0: the 64-B nodes (12 f32: min xyz, max xyz of the left child's box, then of the right child's; two u32 child
  * references; 8 B padding).  which = 1: the 48-B centre / half-extent records the conservative kernels of a
  * RAYCA_BUILDER_SAH scene read instead (RaycaStats.node_format bit 12; 12 f32: centre xyz, half extent xyz per child;
- * the low 16 bits of the x / y half extents of a child hold the low / high half of its reference) -- node i of one is
- * node i of the other.  `bytes_out` receives the array's size; with out == NULL only that.  RAYCA_ERR_BAD_ARG if the
+ * the low 16 bits of the x / y half extents of a child hold the low / high half of its reference, an inner reference
+ * being the child record's byte offset, 48 x its index) -- node i of one is node i of the other.  `bytes_out` receives the array's size; with out == NULL only that.  RAYCA_ERR_BAD_ARG if the
  * scene has no such array or `capacity_bytes` is too small. */
 int32_t rayca_hip_scene_read_nodes(RaycaScene* scene, uint32_t which, void* out, uint64_t capacity_bytes, uint64_t* bytes_out);
 

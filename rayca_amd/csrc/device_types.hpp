@@ -65,6 +65,7 @@ struct DevScene {
   const uint8_t* image_bytes;
   uint32_t material_count, light_count, texture_count, prim_count;
   uint32_t root_ref, root_ref4;
+  uint32_t root_ref_ch;   // the root as nodes_ch's records reference each other (trace_core.inc kChRefScale)
   float root_min[3], root_max[3];
   float cull_abs;  // absolute slack of the best-t cull (see trace())
   uint32_t reserved;

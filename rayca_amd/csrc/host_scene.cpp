@@ -23,8 +23,72 @@
 #include <thread>
 
 #include <sched.h>
+#include <sys/mman.h>
+#include <unordered_map>
 
 namespace rayca {
+
+// ---- the pool behind DefaultInitAllocator (host_scene.hpp) ------------------------------------------------------------------
+namespace {
+struct BigBlockPool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> capacity;            // every live block of the pool, handed out or cached
+  std::vector<std::pair<size_t, void*>> cached;          // (capacity, block) not handed out
+  size_t cached_bytes = 0;
+  size_t limit = [] {
+    const char* e = getenv("RAYCA_HOST_POOL_MB");
+    return (size_t)(e ? std::max(atoi(e), 0) : 1024) << 20;
+  }();
+  ~BigBlockPool() {
+    for (auto& c : cached) std::free(c.second);
+  }
+};
+BigBlockPool& big_pool() {
+  static BigBlockPool* p = new BigBlockPool();   // (never destroyed: vectors of static lifetime may give blocks back at exit)
+  return *p;
+}
+}  // namespace
+void* big_block_take(size_t bytes) {
+  BigBlockPool& bp = big_pool();
+  constexpr size_t kAlign = size_t(2) << 20;
+  const size_t want = (bytes + kAlign - 1) / kAlign * kAlign;
+  {
+    std::lock_guard<std::mutex> lock(bp.mu);
+    size_t best = bp.cached.size();
+    for (size_t i = 0; i < bp.cached.size(); ++i)   // the smallest cached block that fits and is not wastefully large
+      if (bp.cached[i].first >= want && bp.cached[i].first <= 2 * want + (size_t(8) << 20) && (best == bp.cached.size() || bp.cached[i].first < bp.cached[best].first)) best = i;
+    if (best != bp.cached.size()) {
+      void* p = bp.cached[best].second;
+      bp.cached_bytes -= bp.cached[best].first;
+      bp.cached.erase(bp.cached.begin() + (long)best);
+      return p;
+    }
+  }
+  void* p = std::aligned_alloc(kAlign, want);
+  if (!p) throw std::bad_alloc();
+  (void)madvise(p, want, MADV_HUGEPAGE);   // (where the system allows it: 512 times fewer faults on first touch)
+  std::lock_guard<std::mutex> lock(bp.mu);
+  bp.capacity[p] = want;
+  return p;
+}
+void big_block_give(void* p) noexcept {
+  if (!p) return;
+  BigBlockPool& bp = big_pool();
+  bool release = false;
+  {
+    std::lock_guard<std::mutex> lock(bp.mu);
+    auto it = bp.capacity.find(p);
+    if (it == bp.capacity.end()) return;   // (not ours: cannot happen)
+    if (bp.cached_bytes + it->second <= bp.limit && bp.cached.size() < 64) {
+      bp.cached.emplace_back(it->second, p);
+      bp.cached_bytes += it->second;
+    } else {
+      bp.capacity.erase(it);
+      release = true;
+    }
+  }
+  if (release) std::free(p);
+}
 
 unsigned host_threads() {
   static const unsigned n = [] {

@@ -127,12 +127,28 @@ struct HostPrim {
 // std::vector<T>::resize without the zero fill: the flatten order array is ~0.5 KB per triangle (126 MB for the atrium), its
 // slots are written exactly once by the threads that fill them, and value-initialising it first costs a single-threaded
 // pass over all of it (page faults included) -- a quarter of scene_create on the benchmark scene
+//
+// Blocks of 1 MiB and more come from (and go back to) a process-wide pool of 2-MiB-aligned blocks (big_block_take / _give,
+// host_scene.cpp): a host that builds a scene per draw() -- as the reference's draw() does -- touches ~150 MB of fresh pages per
+// build otherwise, and the page faults of those were most of the flatten phases' time (RAYCA_HOST_POOL_MB caps what the pool
+// keeps, default 1024; 0 switches it off).
+void* big_block_take(size_t bytes);
+void big_block_give(void* p) noexcept;
+constexpr size_t kBigBlockMin = size_t(1) << 20;
 template <class T>
 struct DefaultInitAllocator : std::allocator<T> {
   template <class U>
   struct rebind {
     using other = DefaultInitAllocator<U>;
   };
+  T* allocate(size_t n) {
+    if (n * sizeof(T) >= kBigBlockMin) return static_cast<T*>(big_block_take(n * sizeof(T)));
+    return std::allocator<T>::allocate(n);
+  }
+  void deallocate(T* p, size_t n) noexcept {
+    if (n * sizeof(T) >= kBigBlockMin) big_block_give(p);
+    else std::allocator<T>::deallocate(p, n);
+  }
   template <class U, class... Args>
   void construct(U* p, Args&&... args) {
     if constexpr (sizeof...(Args) == 0) ::new (static_cast<void*>(p)) U;

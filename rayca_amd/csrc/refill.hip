@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_REFILL_WAVES) void k_flat_refill(DevS
             float tmin;
             if (STATS) cnt.boxes++;
             cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin)
-                      ? (WIDE ? sc.root_ref4 : sc.root_ref)
+                      ? (WIDE ? sc.root_ref4 : (!HALF && RAYCA_NODE_CH ? sc.root_ref_ch : sc.root_ref))
                       : kTerminated;
             has = true;
           }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_queue_refill(De
           stack.clear();
           float tmin;
           if (STATS) cnt.boxes++;
-          cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? (WIDE ? sc.root_ref4 : sc.root_ref) : kTerminated;
+          cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? (WIDE ? sc.root_ref4 : (!HALF && RAYCA_NODE_CH ? sc.root_ref_ch : sc.root_ref)) : kTerminated;
           has = true;
         }
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock, RAYCA_QREFILL_WAVES) void k_shadow_refill(D
     stack.clear();
     float tmin;
     if (STATS) cnt.boxes++;
-    cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? (WIDE ? sc.root_ref4 : sc.root_ref) : kTerminated;
+    cur = slab(sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2], ray, tmin) ? (WIDE ? sc.root_ref4 : (!HALF && RAYCA_NODE_CH ? sc.root_ref_ch : sc.root_ref)) : kTerminated;
   };
   for (;;) {
     const uint32_t n_active = (uint32_t)__popcll(__ballot(cur != kTerminated));

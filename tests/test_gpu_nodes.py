@@ -52,7 +52,10 @@ def test_centre_half_records_contain_their_boxes(gpu, name):
     assert np.all(h[:, :, 2] <= exact[:, :, 2] * L(1 + 2.0 ** -22) + L(1e-44))
     hb = n48.reshape(-1, 2, 2, 3)[:, :, 1]                                   # the half extents' bits
     ref = (hb[:, :, 0] & 0xFFFF) | ((hb[:, :, 1] & 0xFFFF) << 16)
-    assert np.array_equal(ref[:, 0], n64[:, 12]) and np.array_equal(ref[:, 1], n64[:, 13])
+    want = n64[:, 12:14].copy()
+    inner = ((want & 0x80000000) == 0) & (want != 0x7FFFFFFF)
+    want[inner] *= 48                                                         # (an inner reference is the child record's byte offset)
+    assert np.array_equal(ref, want)
     with pytest.raises(Exception):
         ds.read_nodes(2)
     ds.close()
