@@ -195,19 +195,21 @@ def run_workload(env, args, name, steps, warmup, main):
     tile = tile_of(rank, world, args.band_rows)
     my_rows = int(rows_of(tile, H).numel())
     # F frames in flight: frame i renders with frame context i % F on its own stream into its own buffer, so the tail
-    # of one frame (a few slow waves) overlaps the head of the next; with N > 1 the gather of a finished frame runs on
-    # the comm stream meanwhile.  Every frame is still one complete pass: camera rays -> pixels (-> gather).
+    # of one frame (a few slow waves) overlaps the head of the next; with N > 1 the gather of a finished frame follows it on
+    # the same stream while the other streams render.  Every frame is still one complete pass: camera rays -> pixels (-> gather).
     # measured on one MI355X with every frame stream on a hardware queue of its own (tests/gpu_inflight_probe.py, ms per frame
     # for 1 / 2 / 3 / 4 / 8 frames in flight): whole 1080p frame 0.538 / 0.420 / 0.412 / 0.404 / 0.406, a rank's half
     # 0.334 / 0.256 / 0.228 / 0.220 / 0.220, quarter 0.240 / 0.161 / 0.131 / 0.121 / 0.121, eighth 0.206 / 0.120 / 0.087 /
     # 0.071 / 0.071 -- four, the number of HIP hardware queues (eight queues, GPU_MAX_HW_QUEUES=8, change nothing)
     is_path = int(getattr(cfg, "integrator", 5)) == 5
     wl_generations = int(getattr(cfg, "max_depth", 1)) if is_path else 1
-    # N > 1: three frame streams, so that the comm stream has the fourth hardware queue to itself -- with four frame streams the
-    # gather shares a queue with one of them and a rank's half / quarter / eighth of the 1080p frame takes 0.250 / 0.145 /
-    # 0.100 ms per frame with the per-frame gather instead of 0.212 / 0.131 / 0.097 (tests/gpu_rank_share_probe.py,
-    # profiles/r03_rank_share.log; without a gather four are better: 0.197 / 0.106 / 0.063 against 0.208 / 0.126 / 0.086)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (4 if world == 1 else 3)
+    # N > 1: four frame streams too, and the per-frame gather goes BEHIND ITS FRAME ON THE FRAME'S OWN STREAM (StreamGatherLoop):
+    # stream order is all the ordering there is.  A comm stream of its own shares a hardware queue with one of four frame
+    # streams (or leaves only three for the frames) and costs two event hops per frame: a rank's quarter / eighth of the 1080p
+    # frame with the gather takes 0.099 / 0.062 ms per frame this way, against 0.124 / 0.088 with three frame streams + a
+    # comm stream and 0.135 / 0.095 with four + one (tests/gpu_rank_share_probe.py, profiles/r03_rank_share.log; without a
+    # gather: 0.097 / 0.060), and the rank's host spends 29 us per frame instead of 42-56.
+    F = args.frames_in_flight if args.frames_in_flight > 0 else 4
     F = max(1, min(F, 8))
     outs = [torch.empty((my_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
     out = outs[0]
@@ -271,6 +273,34 @@ def run_workload(env, args, name, steps, warmup, main):
                 self.flush((self.counter // self.B) % 2, self.counter % self.B)
             self.counter = 0
 
+    class StreamGatherLoop:
+        """K frames, one gather per frame (the north-star shape), issued behind the frame on the frame's stream: context c
+        renders into its own send buffer, the collective and (rank 0) the de-interleave follow in stream order, the next frame
+        of that context queues behind them.  No comm stream, no events; the F streams run F such chains side by side.  The
+        collectives are issued in the same round-robin order on every rank."""
+        B = 1
+
+        def __init__(self):
+            self.counter = 0
+            self.gatherer = FrameGatherer(H, W, args.band_rows, gather_dev)
+            self.sends = [torch.zeros((self.gatherer.max_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
+            self.frames = [torch.empty((H, W, 4), dtype=torch.uint8, device=gather_dev) if rank == 0 else None for _ in range(F)]
+            self.issue = [ds.prepare_device(cfg, W, H, self.sends[c][:my_rows].data_ptr(), 0, tile=tile, stream=streams[c].cuda_stream, context=c) for c in range(F)]
+            torch.cuda.synchronize()
+
+        def step(self):
+            c = self.counter % F
+            self.counter += 1
+            self.issue[c]()
+            with torch.cuda.stream(streams[c]):
+                if backend == "nccl":
+                    return self.gatherer(self.sends[c], out=self.frames[c])
+                streams[c].synchronize()   # rehearsal: gloo gathers host tensors
+                return self.gatherer(self.sends[c].cpu(), out=self.frames[c])
+
+        def drain(self):
+            self.counter = 0
+
     class LocalLoop:
         """N = 1: no exchange, the frame stays in device memory."""
         B = 1
@@ -328,7 +358,7 @@ def run_workload(env, args, name, steps, warmup, main):
         elapsed = timed(LocalLoop())
         elapsed_batched, B2 = None, 1
     else:
-        elapsed = timed(GatherLoop(1))                       # `value`: one gather per frame
+        elapsed = timed(StreamGatherLoop())                  # `value`: one gather per frame
         B2 = max(1, min(args.gather_batch, 8))
         elapsed_batched = timed(GatherLoop(B2)) if (B2 > 1 and main) else None
 
@@ -468,7 +498,7 @@ def run_workload(env, args, name, steps, warmup, main):
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
-                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, ONE collective per frame at frame end, on its own stream"
+                   "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, ONE collective per frame at frame end, behind the frame on the frame's own stream"
                                     if world > 1 else "none"),
                    "launched_by": "torch.distributed.run / environment" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py (rayca_amd/launcher.py)" if world > 1 else "single process")},
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,

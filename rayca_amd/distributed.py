@@ -73,7 +73,7 @@ class FrameGatherer:
         if self.world == 1:
             return local_rows
         send = local_rows
-        if self.pad is not None:
+        if self.pad is not None and local_rows.shape[0] != self.max_rows:   # (a caller may render straight into a full-size buffer)
             self.pad[: self.my_rows].copy_(local_rows)
             send = self.pad
         dist.gather(send, self.views, dst=self.dst, group=self.group)

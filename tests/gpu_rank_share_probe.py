@@ -35,10 +35,13 @@ for parts in parts_list:
     for F in [int(x) for x in os.environ.get("RAYCA_PROBE_F", "4").split(",")]:
         streams = early_streams[8 - F:8]
         comm = early_streams[8]
-        sends = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
+        # RAYCA_PROBE_BUFS send buffers per frame context, used in turn: with one, a context's next frame waits for the gather of
+        # its previous one (render -> gather -> render is one dependent chain per context); with two it only waits for the render
+        NB = F * int(os.environ.get("RAYCA_PROBE_BUFS", "1"))
+        sends = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(NB)]
         recv = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev)]
-        ev = [torch.cuda.Event() for _ in range(F)]
-        evg = [torch.cuda.Event() for _ in range(F)]
+        ev = [torch.cuda.Event() for _ in range(NB)]
+        evg = [torch.cuda.Event() for _ in range(NB)]
         for e in ev + evg:
             e.record(comm)
         for i in range(F):   # contexts warm, node format decided
@@ -46,11 +49,15 @@ for parts in parts_list:
                 ds.render_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i, want_stats=True)
         torch.cuda.synchronize()
         if single_call:
-            issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i,
-                                       wait_event=evg[i].cuda_event, record_event=ev[i].cuda_event) for i in range(F)]
+            issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i % F].cuda_stream, context=i % F,
+                                       wait_event=evg[i].cuda_event, record_event=ev[i].cuda_event) for i in range(NB)]
         else:
-            issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i].cuda_stream, context=i) for i in range(F)]
+            issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i % F].cuda_stream, context=i % F) for i in range(NB)]
         comm_thread = os.environ.get("RAYCA_PROBE_COMM_THREAD", "0") == "1"
+        on_frame_stream = os.environ.get("RAYCA_PROBE_COMM", "") == "frame"
+        if on_frame_stream:   # (stream order is all the ordering there is: no events)
+            issue = [ds.prepare_device(cfg, W, H, sends[i].data_ptr(), 0, tile=tile, stream=streams[i % F].cuda_stream, context=i % F) for i in range(NB)]
+            single_call_here = True
         if comm_thread:   # the collectives issued by a thread of their own: the frame loop only hands it frame indices
             import queue, threading
             jobs = queue.SimpleQueue()
@@ -111,15 +118,18 @@ for parts in parts_list:
                 print(f"{wl} parts {parts} ({rows} rows) F={F} comm thread     gather=per frame: {ms:.4f} ms/frame, host (frame loop) {host / K * 1e6:.1f} us/frame  -> {parts}-GPU frame rate {scale}", flush=True)
                 continue
             for k in range(K):
-                i = k % F
+                i = k % NB
                 h0 = time.perf_counter()
-                if single_call:
+                if single_call or on_frame_stream:
                     issue[i]()
                 else:
-                    streams[i].wait_event(evg[i])
+                    streams[i % F].wait_event(evg[i])
                     issue[i]()
-                    ev[i].record(streams[i])
-                if gather:
+                    ev[i].record(streams[i % F])
+                if gather and on_frame_stream:   # RAYCA_PROBE_COMM=frame: the collective behind the frame on the frame's own stream
+                    with torch.cuda.stream(streams[i % F]):
+                        dist.gather(sends[i], recv, dst=0)
+                elif gather:
                     with torch.cuda.stream(comm):
                         comm.wait_event(ev[i])
                         dist.gather(sends[i], recv, dst=0)
@@ -130,7 +140,7 @@ for parts in parts_list:
             if parts == 1 and not gather:
                 whole_ms = ms   # one GPU's own frame time, measured here: what the shares are compared with
             scale = f"x{whole_ms / ms:.2f} of one GPU's" if whole_ms else "(run with parts 1 first for the ratio)"
-            print(f"{wl} parts {parts} ({rows} rows) F={F} calls/frame={'1' if single_call else '3'} gather={'per frame' if gather else 'none':9s}: {ms:.4f} ms/frame, host {host / K * 1e6:.1f} us/frame  -> {parts}-GPU frame rate {scale}", flush=True)
+            print(f"{wl} parts {parts} ({rows} rows) F={F} bufs={NB} calls/frame={'1' if single_call else '3'}{' gather on the frame stream' if on_frame_stream else ''} gather={'per frame' if gather else 'none':9s}: {ms:.4f} ms/frame, host {host / K * 1e6:.1f} us/frame  -> {parts}-GPU frame rate {scale}", flush=True)
 if os.environ.get("RAYCA_PROBE_COMM_THREAD", "0") == "1":
     jobs.put(None)
 dist.destroy_process_group()

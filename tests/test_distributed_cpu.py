@@ -48,7 +48,17 @@ def _worker(rank, world, port, height, width, band, out_path):
     send1[0, : g1.my_rows] = torch.from_numpy(u8)
     one = g1.gather_batch(send1)
     assert (one is None) == (rank != 0)
+    # the call shape of bench.py's per-frame gather (StreamGatherLoop): the frame is rendered straight into a full-size
+    # (max_rows) send buffer, ragged heights included, and gathered with out= a buffer that is reused
+    gs = FrameGatherer(height, width, band, "cpu")
+    full_send = torch.zeros((gs.max_rows, width, 4), dtype=torch.uint8)
+    full_send[: gs.my_rows] = torch.from_numpy(u8)
+    reuse = torch.empty((height, width, 4), dtype=torch.uint8) if rank == 0 else None
+    for _ in range(2):
+        streamed = gs(full_send, out=reuse)
+    assert (streamed is None) == (rank != 0)
     if rank == 0:
+        assert streamed is reuse and np.array_equal(streamed.numpy(), frame.numpy())
         full, _, _ = orc.render(cfg, width, height, want_f32=False)
         assert np.array_equal(one[0].numpy(), frame.numpy())
         assert np.array_equal(batch[0].numpy(), frame.numpy())
