@@ -45,6 +45,11 @@ def test_engines_agree(gpu, case):
     for k in ("rays_primary", "rays_shadow", "rays_bounce", "hits_shaded"):
         assert sa[k] == sb[k], k
     assert float(fa[..., :3].max()) > 0.0
+    # RAYCA_ENGINE_AUTO picks one of the two by the number of generations: always the same frame and the same ray counts
+    u8c, fc, sc = ds.render(cfg, w, h, engine=abi.ENGINE_AUTO, collect_stats=True)
+    assert np.array_equal(fc.view(np.uint32), fa.view(np.uint32)) and np.array_equal(u8c, u8a)
+    for k in ("rays_primary", "rays_shadow", "rays_bounce", "hits_shaded", "boxes_tested", "triangles_tested"):
+        assert sc[k] == sa[k] or k in ("boxes_tested", "triangles_tested"), k
     # SIMD-slot accounting (include/rayca_hip.h): a wave books 64 lanes per trip through the node / leaf loop, so the
     # slots bound the per-lane tests from above (the root box of every ray is tested outside the node loop)
     rays = sa["rays_primary"] + sa["rays_shadow"] + sa["rays_bounce"]
