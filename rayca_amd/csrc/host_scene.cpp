@@ -1191,7 +1191,10 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   struct TriJob {  // a run of triangles of one mesh primitive under one node, and where its HostPrims go
     uint32_t node, pi, first_tri, first_out, count;
     Mat3 tangent_matrix, normal_matrix;
+    uint32_t model, blas_pos;   // its BLAS and the position of its first triangle in that BLAS's initial order
   };
+  struct OtherPrim { uint32_t prim, model, blas_pos; };   // spheres, quad-light triangles: made where they are met, few
+  std::vector<OtherPrim> others;
   std::vector<TriJob> jobs;
   std::vector<HostBlas> blas(models.size());
   {  // one allocation for the flatten-order array: growing it piecewise re-copied 0.5 KB per triangle several times over
@@ -1228,6 +1231,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           ext.kind = hp.kind;
           ext.node = node;
           hp.src = (uint32_t)s.prims.size();
+          others.push_back(OtherPrim{hp.src, (uint32_t)m, (uint32_t)blas[m].prims.size()});
           blas[m].prims.push_back(hp.src);
           s.prims.push_back(hp);
           s.ext.push_back(ext);
@@ -1239,7 +1243,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         const uint32_t ntri = p.index_count / 3;
         const uint32_t first_out = (uint32_t)s.prims.size();
         for (uint32_t at = 0; at < ntri; at += 8192)  // pieces, so that one huge mesh still feeds every thread
-          jobs.push_back(TriJob{node, pi, at, first_out + at, std::min<uint32_t>(8192u, ntri - at), tangent_matrix, normal_matrix});
+          jobs.push_back(TriJob{node, pi, at, first_out + at, std::min<uint32_t>(8192u, ntri - at), tangent_matrix, normal_matrix, (uint32_t)m,
+                                (uint32_t)blas[m].prims.size() + at});
         s.prims.resize((size_t)first_out + ntri);
         s.ext.resize((size_t)first_out + ntri);
         {
@@ -1274,6 +1279,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
         ext.kind = hp.kind;
         ext.node = node;
         hp.src = (uint32_t)s.prims.size();
+        others.push_back(OtherPrim{hp.src, (uint32_t)m, (uint32_t)blas[m].prims.size()});
         blas[m].prims.push_back(hp.src);
         s.prims.push_back(hp);
         s.ext.push_back(ext);
@@ -1282,6 +1288,35 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     }
   }
   lap("flatten: graph, slots");
+  // One pass over the triangles does everything that is per primitive: the flatten-order record and its shading record, the
+  // world-space vertices / centroid / box (cache_world), the 9 floats of the device's triangle array, and -- for a BLAS the
+  // device builds -- its row of the SoA the device builder reads.  (Three passes of all host threads before: each touched
+  // the 0.5 KB per primitive again and paid a round of thread starts.)
+  static const bool host_only = getenv("RAYCA_HOST_BUILD") != nullptr;
+  const BlasBuildFn device_builder = g_device_builder;   // (thread_local: captured here, the trees are built by other threads)
+  using Soa = std::vector<float, DefaultInitAllocator<float>>;   // nine planes of n floats, one block, BLAS order
+  std::vector<Soa> soas(blas.size());
+  for (size_t m = 0; m < blas.size(); ++m)
+    if (device_builder && !host_only && use_bvh && blas[m].prims.size() >= kDeviceBuildMin) soas[m].resize(9 * blas[m].prims.size());
+  s.tris.resize(s.prims.size() * 9);
+  auto finish_prim = [&](uint32_t prim, uint32_t model, uint32_t blas_pos) {
+    HostPrim& p = s.prims[prim];
+    cache_world(p, s.world_trs[p.node]);
+    float* tv = &s.tris[(size_t)prim * 9];
+    for (int k = 0; k < 3; ++k) {
+      tv[3 * k + 0] = p.wp[k].x;
+      tv[3 * k + 1] = p.wp[k].y;
+      tv[3 * k + 2] = p.wp[k].z;
+    }
+    Soa& soa = soas[model];
+    if (!soa.empty()) {
+      const size_t n = soa.size() / 9, i = blas_pos;
+      float* const q = soa.data();
+      q[i] = p.wcentroid.x; q[n + i] = p.wcentroid.y; q[2 * n + i] = p.wcentroid.z;
+      q[3 * n + i] = p.wmin.x; q[4 * n + i] = p.wmin.y; q[5 * n + i] = p.wmin.z;
+      q[6 * n + i] = p.wmax.x; q[7 * n + i] = p.wmax.y; q[8 * n + i] = p.wmax.z;
+    }
+  };
   if (!jobs.empty()) {  // fill the reserved triangle slots with all host threads
     std::atomic<int> failed{0};
     const char* first_error = nullptr;
@@ -1325,6 +1360,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
           ext.kind = hp.kind;
           ext.node = job.node;
           hp.src = job.first_out + t;
+          finish_prim(job.first_out + t, job.model, job.blas_pos + t);
         }
       }
     };
@@ -1335,21 +1371,8 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
     for (std::thread& th : pool) th.join();
     if (failed.load()) { err = first_error ? first_error : "bad triangle data"; return RAYCA_ERR_BAD_ARG; }
   }
-  lap("flatten primitives");
-  s.tris.resize(s.prims.size() * 9);
-  parallel_chunks(s.prims.size(), [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; ++i) {
-      HostPrim& p = s.prims[i];
-      cache_world(p, s.world_trs[p.node]);
-      float* tv = &s.tris[i * 9];
-      for (int k = 0; k < 3; ++k) {
-        tv[3 * k + 0] = p.wp[k].x;
-        tv[3 * k + 1] = p.wp[k].y;
-        tv[3 * k + 2] = p.wp[k].z;
-      }
-    }
-  });
-  lap("world-space vertices, boxes");
+  for (const OtherPrim& o : others) finish_prim(o.prim, o.model, o.blas_pos);
+  lap("flatten primitives, world space, SoA");
   if (hooks.on_prims_ready) hooks.on_prims_ready();
 
   // ---- Tlas::new: one BLAS per model ------------------------------------------------------------
@@ -1360,9 +1383,6 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   // reference order of every primitive inside its BLAS (needed by both builders: it is the tie rule)
   std::vector<std::vector<uint32_t>> ref_prims(blas.size());
   std::vector<std::vector<BuildNode>> ref_nodes(blas.size());
-  static const bool host_only = getenv("RAYCA_HOST_BUILD") != nullptr;
-  // (thread_local: captured here because the two trees of a RAYCA_BUILDER_SAH scene are built by two threads)
-  const BlasBuildFn device_builder = g_device_builder;
   const uint32_t device_ordinal = g_device_ordinal;
   std::mutex lap_mu;
   // the traversed tree of a device-built BLAS stays on the device and is laid out there (HostBlas::dev_tree) -- unless the
@@ -1377,20 +1397,6 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   s.dev_trees.clear();
   // what the device builder reads: world centroids and boxes of a BLAS's primitives, SoA, in the BLAS's initial order (the
   // two trees of a RAYCA_BUILDER_SAH scene start from the same order and share one copy)
-  using Soa = std::vector<float, DefaultInitAllocator<float>>;   // nine planes of n floats, one block
-  auto make_soa = [&](const std::vector<uint32_t>& order, Soa& soa) {
-    const size_t n = order.size();
-    soa.resize(9 * n);
-    float* const q = soa.data();
-    parallel_chunks(n, [&](size_t b, size_t e) {
-      for (size_t i = b; i < e; ++i) {
-        const HostPrim& p = s.prims[order[i]];
-        q[i] = p.wcentroid.x; q[n + i] = p.wcentroid.y; q[2 * n + i] = p.wcentroid.z;
-        q[3 * n + i] = p.wmin.x; q[4 * n + i] = p.wmin.y; q[5 * n + i] = p.wmin.z;
-        q[6 * n + i] = p.wmax.x; q[7 * n + i] = p.wmax.y; q[8 * n + i] = p.wmax.z;
-      }
-    });
-  };
   auto build_blas = [&](size_t m, bool seed_origin, std::vector<uint32_t>& order, std::vector<BuildNode>& nodes, std::string& build_err, bool quiet,
                         const Soa& soa, BlasDeviceTree* keep, void* stream) {
     auto lap = [&](const char* what) {
@@ -1443,11 +1449,7 @@ int32_t build_host_scene(const RaycaSceneDesc& d, bool use_bvh, uint32_t builder
   };
   for (size_t m = 0; m < blas.size(); ++m) {
     std::string e1, e2;
-    Soa soa;
-    if (device_builder && !host_only && use_bvh && blas[m].prims.size() >= kDeviceBuildMin) {
-      make_soa(blas[m].prims, soa);
-      lap("  host: SoA of centroids/boxes");
-    }
+    Soa& soa = soas[m];   // (filled by the flatten pass for the BLASes the device builds)
     if (builder == RAYCA_BUILDER_SAH) {
       // two independent trees over the same primitives -- the reference's (tie order + candidate filter) and the one that
       // is traversed -- built side by side: one's host phases (SoA, order, layout) run under the other's GPU levels
