@@ -630,27 +630,53 @@ __global__ void k_layout_parents(LayoutState ls) {
     ls.parent[nd.right] = i;
   }
 }
+// The records that travel between threads of DIFFERENT workgroups (a child's record is read by whoever finishes its parent)
+// are written and read with agent-scope relaxed atomics -- accesses that are coherent across the XCDs' L2s on their own -- and
+// ordered by hand: a record's stores are acknowledged (s_waitcnt) before the arrival count is bumped, and the sibling's record
+// is fetched after the bump has returned.  An ACQ_REL agent-scope atomic does the same job with a write-back and an
+// invalidate of the whole L2 around EVERY bump: k_layout_sizes took 1.5 ms for the atrium's 543 k nodes that way (average
+// vector-memory latency 50 000 cycles, profiles/r03_atrium_diag_pmc.txt).
+__device__ __forceinline__ void rec_store(uint4* rec, uint4 v) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(rec);
+  __hip_atomic_store(w + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint4 rec_load(const uint4* rec) {
+  uint32_t* w = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(rec));
+  uint4 v;
+  v.x = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.w = __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+__device__ __forceinline__ void memory_ops_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
 __global__ void k_layout_sizes(LayoutState ls) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ls.node_count) return;
   const DNode nd = ls.nodes[i];
   if (nd.left >= 0) return;  // leaves start the climb
   const uint32_t chain = chain_nodes(nd.count);
-  ls.rec[i] = make_uint4(chain, chain ? 1u : 0u, nd.count, __float_as_uint((float)nd.count * area3(nd.a, nd.b)));
+  rec_store(&ls.rec[i], make_uint4(chain, chain ? 1u : 0u, nd.count, __float_as_uint((float)nd.count * area3(nd.a, nd.b))));
   ls.leafed[i] = 0u;
   uint32_t p = ls.parent[i];
   while (p != RAYCA_NONE) {
-    // release: the record above (or the one written at the end of the last trip) is visible before the count is; acquire:
-    // the second child to arrive sees its sibling's record
-    if (__hip_atomic_fetch_add(&ls.arrived[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // the sibling subtree is not finished: its last thread goes on
+    // the record above (or the one written at the end of the last trip) has landed before the count is bumped; the second
+    // child to arrive reads its sibling's record after its own bump has come back
+    memory_ops_done();
+    if (__hip_atomic_fetch_add(&ls.arrived[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // the sibling subtree is not finished: its last thread goes on
+    memory_ops_done();
     const DNode pn = ls.nodes[p];
-    const uint4 l = ls.rec[pn.left], r = ls.rec[pn.right];
+    const uint4 l = rec_load(&ls.rec[pn.left]), r = rec_load(&ls.rec[pn.right]);
     const uint32_t pl = l.z, pr = r.z;
     const float area = area3(pn.a, pn.b), as_leaf = (float)(pl + pr) * area, as_split = ls.node_cost * area + __uint_as_float(l.w) + __uint_as_float(r.w);
     // (the whole subtree becomes one leaf reference in its parent: no nodes of its own)
     const bool one_leaf = ls.node_cost > 0.0f && pl + pr <= ls.leaf_max && as_leaf <= as_split;
     ls.leafed[p] = one_leaf ? 1u : 0u;
-    ls.rec[p] = make_uint4(one_leaf ? 0u : 1u + l.x + r.x, one_leaf ? 0u : 1u + (l.y > r.y ? l.y : r.y), pl + pr, __float_as_uint(one_leaf ? as_leaf : as_split));
+    rec_store(&ls.rec[p], make_uint4(one_leaf ? 0u : 1u + l.x + r.x, one_leaf ? 0u : 1u + (l.y > r.y ? l.y : r.y), pl + pr, __float_as_uint(one_leaf ? as_leaf : as_split)));
     p = ls.parent[p];
   }
 }
