@@ -57,7 +57,24 @@ static_assert(sizeof(DNode) == sizeof(BuildNode) && offsetof(DNode, b) == offset
               offsetof(DNode, left) == offsetof(BuildNode, left) && offsetof(DNode, right) == offsetof(BuildNode, right),
               "DNode is downloaded into a std::vector<BuildNode>");
 
+// RAYCA_BIG_PARTITION: the swap partition of a node that is binned by many workgroups (more than kBig primitives) is solved by
+// many workgroups too -- one per kChunk positions, the chunks k_bin_big already works through -- in a handful of small
+// launches per level (k_big_*), instead of by the ONE workgroup that runs the node in k_build_level: that workgroup took
+// 2.4 ms for the atrium's root and the top levels were half of the level loop.  Same destinations (same ranks of holes and
+// fillers), so the same order.
+#ifndef RAYCA_BIG_PARTITION
+#define RAYCA_BIG_PARTITION 1
+#endif
+struct BigSplit {          // one big node of the current level, by its bin slot
+  uint32_t node, axis, ok, nl, n, off, holes;
+  uint32_t chunk_first;    // its first entry in the level's chunk list (written when the list was made, a level earlier)
+  float pos;
+  uint32_t box[2][2][3];   // the children's boxes: [child][min / max][xyz], encoded for atomicMin / atomicMax
+};
 struct BuildState {
+  BigSplit* splits[2];   // this level's / the next level's (level parity)
+  uint32_t* ch_cnt;      // per chunk of the level's list: holes, fillers in it
+  uint32_t* ch_base;     // per chunk: rank of its first hole (ascending), of its last filler (descending)
   const float* cent[3];  // centroid, SoA, by primitive id
   const float* bmin[3];
   const float* bmax[3];
@@ -196,6 +213,49 @@ __global__ __launch_bounds__(kB) void k_bin_big(BuildState st, const uint2* chun
   }
 }
 
+// the two children of `node_id` (range [off, off + n) split at nl): arena nodes, big slots and chunk lists of the big ones,
+// and where each goes next -- the next level's list, or k_build_small.  box: [child][min / max][xyz], encoded.  One thread.
+__device__ void make_children(const BuildState& st, uint32_t node_id, uint32_t off, uint32_t n, uint32_t nl, const uint32_t* box, uint32_t* next,
+                              uint32_t* next_count, uint2* next_chunks, uint32_t level) {
+  const uint32_t base = atomicAdd(st.node_count, 2u);
+  DNode l, r;
+  for (int c = 0; c < 3; ++c) {
+    l.a[c] = dec(box[0 * 6 + 0 * 3 + c]); l.b[c] = dec(box[0 * 6 + 1 * 3 + c]);
+    r.a[c] = dec(box[1 * 6 + 0 * 3 + c]); r.b[c] = dec(box[1 * 6 + 1 * 3 + c]);
+  }
+  l.a[3] = l.b[3] = r.a[3] = r.b[3] = 1.0f;
+  l.offset = off; l.count = nl; l.left = l.right = -1;
+  r.offset = off + nl; r.count = n - nl; r.left = r.right = -1;
+  const uint32_t big2[2] = {nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE, n - nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE};
+  st.big[base] = big2[0];
+  st.big[base + 1] = big2[1];
+  for (uint32_t c = 0; c < 2; ++c) {
+    const DNode& ch = c ? r : l;
+    if (big2[c] == RAYCA_NONE) continue;
+    const uint32_t nch = (ch.count + kChunk - 1) / kChunk;
+    const uint32_t at = atomicAdd(st.chunk_count, nch);
+    for (uint32_t k = 0; k < nch; ++k) next_chunks[at + k] = make_uint2(base + c, k);
+    st.splits[(level + 1u) & 1u][big2[c]].chunk_first = at;
+  }
+  st.nodes[base] = l;
+  st.nodes[base + 1] = r;
+  st.nodes[node_id].left = (int32_t)base;
+  st.nodes[node_id].right = (int32_t)base + 1;
+  st.nodes[node_id].count = 0;  // inner
+  for (uint32_t c = 0; c < 2; ++c) {
+    const uint32_t cn = c ? n - nl : nl;
+    if (cn <= kSeq) {
+      if (cn > 1) {  // a single primitive can never be split: nothing left to do
+        const uint32_t slot = atomicAdd(st.small_count, 1u);
+        st.small_nodes[slot] = base + c;
+        st.small_levels[slot] = level + 1u;
+      }
+    } else {
+      next[atomicAdd(next_count, 1u)] = base + c;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBuildLevelMaxBlock) void k_build_level(BuildState st, const uint32_t* active, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level,
                                                                   const uint32_t* lc) {
   if (blockIdx.x >= lc[0]) return;   // (block-uniform: before any barrier)
@@ -303,6 +363,21 @@ __global__ __launch_bounds__(kBuildLevelMaxBlock) void k_build_level(BuildState 
     s_left = 0;
   }
   __syncthreads();
+#if RAYCA_BIG_PARTITION
+  if (nd_big != RAYCA_NONE) {  // the decision only: k_big_* partition the range and make the children
+    if (tid == 0) {
+      BigSplit& d = st.splits[level & 1u][nd_big];
+      d.node = node_id; d.axis = (uint32_t)s_axis; d.ok = s_split_ok; d.nl = 0u; d.n = n; d.off = off; d.holes = 0u;
+      d.pos = s_best_pos;
+      for (int c = 0; c < 2; ++c)
+        for (int k = 0; k < 3; ++k) {
+          d.box[c][0][k] = enc(FLT_MAX);
+          d.box[c][1][k] = enc(-FLT_MAX);
+        }
+    }
+    return;
+  }
+#endif
   if (!s_split_ok) return;  // a leaf: primitives stay as they are
 
   // ---- 3. the swap partition, solved ------------------------------------------------------------------------------
@@ -389,45 +464,185 @@ __global__ __launch_bounds__(kBuildLevelMaxBlock) void k_build_level(BuildState 
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    const uint32_t base = atomicAdd(st.node_count, 2u);
-    DNode l, r;
-    for (int c = 0; c < 3; ++c) {
-      l.a[c] = dec(s_red[0][0][c]); l.b[c] = dec(s_red[0][1][c]);
-      r.a[c] = dec(s_red[1][0][c]); r.b[c] = dec(s_red[1][1][c]);
+  if (tid == 0) make_children(st, node_id, off, n, nl, &s_red[0][0][0], next, next_count, next_chunks, level);
+}
+
+#if RAYCA_BIG_PARTITION
+// ---- the partition of the big nodes, one workgroup per chunk (the level's chunk list; lc[1] entries, lc[2] slots) ---------------
+__device__ __forceinline__ bool big_job(const BuildState& st, const uint2* chunks, const uint32_t* lc, uint32_t level, uint2& job, BigSplit*& d, uint32_t& begin, uint32_t& end) {
+  if (blockIdx.x >= lc[1]) return false;   // (block-uniform)
+  job = chunks[blockIdx.x];
+  d = &st.splits[level & 1u][st.big[job.x]];
+  begin = job.y * kChunk;
+  end = min(d->n, begin + kChunk);
+  return d->ok != 0u;
+}
+// left-class primitives of the node: nl
+__global__ __launch_bounds__(kB) void k_big_count(BuildState st, const uint2* chunks, const uint32_t* lc, uint32_t level) {
+  __shared__ uint32_t s_left;
+  uint2 job; BigSplit* d; uint32_t begin, end;
+  if (!big_job(st, chunks, lc, level, job, d, begin, end)) return;
+  if (threadIdx.x == 0) s_left = 0;
+  __syncthreads();
+  const float* cax = st.cent[d->axis];
+  const float pos = d->pos;
+  uint32_t part = 0;
+  for (uint32_t p = begin + threadIdx.x; p < end; p += blockDim.x) part += cax[st.order[d->off + p]] < pos ? 1u : 0u;
+  if (part) atomicAdd(&s_left, part);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_left) atomicAdd(&d->nl, s_left);
+}
+// holes (right-class below nl) and fillers (left-class from nl on) of every chunk
+__global__ __launch_bounds__(kB) void k_big_classify(BuildState st, const uint2* chunks, const uint32_t* lc, uint32_t level) {
+  __shared__ uint32_t s_h, s_f;
+  uint2 job; BigSplit* d; uint32_t begin, end;
+  if (!big_job(st, chunks, lc, level, job, d, begin, end)) return;
+  const uint32_t nl = d->nl;
+  if (nl == 0u || nl == d->n) return;
+  if (threadIdx.x == 0) s_h = s_f = 0;
+  __syncthreads();
+  const float* cax = st.cent[d->axis];
+  const float pos = d->pos;
+  uint32_t h = 0, f = 0;
+  for (uint32_t p = begin + threadIdx.x; p < end; p += blockDim.x) {
+    const bool left = cax[st.order[d->off + p]] < pos;
+    h += (p < nl && !left) ? 1u : 0u;
+    f += (p >= nl && left) ? 1u : 0u;
+  }
+  if (h) atomicAdd(&s_h, h);
+  if (f) atomicAdd(&s_f, f);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st.ch_cnt[2u * blockIdx.x] = s_h;
+    st.ch_cnt[2u * blockIdx.x + 1u] = s_f;
+  }
+}
+// per node: rank of every chunk's first hole (holes ranked ascending) and of its last filler (fillers ranked from the end)
+__global__ void k_big_scan(BuildState st, const uint32_t* lc, uint32_t level) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= lc[2]) return;
+  BigSplit& d = st.splits[level & 1u][slot];
+  if (!d.ok || d.nl == 0u || d.nl == d.n) return;
+  const uint32_t nch = (d.n + kChunk - 1) / kChunk, cf = d.chunk_first;
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < nch; ++k) {
+    st.ch_base[2u * (cf + k)] = run;
+    run += st.ch_cnt[2u * (cf + k)];
+  }
+  d.holes = run;
+  run = 0;
+  for (uint32_t k = nch; k-- > 0;) {
+    st.ch_base[2u * (cf + k) + 1u] = run;
+    run += st.ch_cnt[2u * (cf + k) + 1u];
+  }
+}
+// ranks and positions of the holes and fillers (what the one-workgroup form keeps in rank / hole_pos / filler_pos)
+__global__ __launch_bounds__(kB) void k_big_rank(BuildState st, const uint2* chunks, const uint32_t* lc, uint32_t level) {
+  __shared__ uint32_t s_wave[kB / 64];
+  uint2 job; BigSplit* d; uint32_t begin, end;
+  if (!big_job(st, chunks, lc, level, job, d, begin, end)) return;
+  const uint32_t nl = d->nl, off = d->off;
+  if (nl == 0u || nl == d->n) return;
+  const float* cax = st.cent[d->axis];
+  const float pos = d->pos;
+  uint32_t run = st.ch_base[2u * blockIdx.x];
+  for (uint32_t base = begin; base < end; base += blockDim.x) {   // holes, ascending
+    const uint32_t p = base + threadIdx.x;
+    const bool is_hole = p < end && p < nl && !(cax[st.order[off + p]] < pos);
+    uint32_t tot;
+    const uint32_t r = run + block_prefix(is_hole, s_wave, tot);
+    if (is_hole) {
+      st.hole_pos[off + r] = p;
+      st.rank[off + p] = r;
     }
-    l.a[3] = l.b[3] = r.a[3] = r.b[3] = 1.0f;
-    l.offset = off; l.count = nl; l.left = l.right = -1;
-    r.offset = off + nl; r.count = n - nl; r.left = r.right = -1;
-    const uint32_t big2[2] = {nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE, n - nl > kBig ? atomicAdd(st.slot_count, 1u) : RAYCA_NONE};
-    st.big[base] = big2[0];
-    st.big[base + 1] = big2[1];
-    for (uint32_t c = 0; c < 2; ++c) {
-      const DNode& ch = c ? r : l;
-      if (big2[c] == RAYCA_NONE) continue;
-      const uint32_t nch = (ch.count + kChunk - 1) / kChunk;
-      const uint32_t at = atomicAdd(st.chunk_count, nch);
-      for (uint32_t k = 0; k < nch; ++k) next_chunks[at + k] = make_uint2(base + c, k);
+    run += tot;
+  }
+  run = st.ch_base[2u * blockIdx.x + 1u];
+  for (uint32_t back = 0; back < end - begin; back += blockDim.x) {   // fillers, from the chunk's end down
+    const uint32_t q = back + threadIdx.x;
+    const bool in = q < end - begin;
+    const uint32_t p = in ? end - 1u - q : 0u;
+    const bool is_filler = in && p >= nl && cax[st.order[off + p]] < pos;
+    uint32_t tot;
+    const uint32_t r = run + block_prefix(is_filler, s_wave, tot);
+    if (is_filler) {
+      st.filler_pos[off + r] = p;
+      st.rank[off + p] = r;
     }
-    st.nodes[base] = l;
-    st.nodes[base + 1] = r;
-    st.nodes[node_id].left = (int32_t)base;
-    st.nodes[node_id].right = (int32_t)base + 1;
-    st.nodes[node_id].count = 0;  // inner
-    for (uint32_t c = 0; c < 2; ++c) {
-      const uint32_t cn = c ? n - nl : nl;
-      if (cn <= kSeq) {
-        if (cn > 1) {  // a single primitive can never be split: nothing left to do
-          const uint32_t slot = atomicAdd(st.small_count, 1u);
-          st.small_nodes[slot] = base + c;
-          st.small_levels[slot] = level + 1u;
+    run += tot;
+  }
+}
+// every primitive to its place (tmp)
+__global__ __launch_bounds__(kB) void k_big_scatter(BuildState st, const uint2* chunks, const uint32_t* lc, uint32_t level) {
+  uint2 job; BigSplit* d; uint32_t begin, end;
+  if (!big_job(st, chunks, lc, level, job, d, begin, end)) return;
+  const uint32_t nl = d->nl, n = d->n, off = d->off, K = d->holes;
+  if (nl == n) return;   // everything left of the plane: the loop never swaps
+  const float* cax = st.cent[d->axis];
+  const float pos = d->pos;
+  for (uint32_t p = begin + threadIdx.x; p < end; p += blockDim.x) {
+    const uint32_t id = st.order[off + p];
+    uint32_t dest;
+    if (nl == 0u) {   // everything right: the loop rotates the range (first element to the end, the others down by one)
+      dest = p == 0u ? n - 1u : p - 1u;
+    } else {
+      const bool left = cax[id] < pos;
+      if (p < nl) {
+        if (left) dest = p;
+        else {
+          const uint32_t k = st.rank[off + p];
+          dest = k == 0 ? n - 1 : st.filler_pos[off + k - 1] - 1;
         }
+      } else if (left) {
+        dest = st.hole_pos[off + st.rank[off + p]];
+      } else if (p == nl) {
+        dest = (K == 0 ? n : st.filler_pos[off + K - 1]) - 1;
       } else {
-        next[atomicAdd(next_count, 1u)] = base + c;
+        dest = p - 1;
+      }
+    }
+    st.tmp[off + dest] = id;
+  }
+}
+// back into the order, and the children's boxes
+__global__ __launch_bounds__(kB) void k_big_finish(BuildState st, const uint2* chunks, const uint32_t* lc, uint32_t level) {
+  __shared__ uint32_t s_red[2][2][3];
+  uint2 job; BigSplit* d; uint32_t begin, end;
+  if (!big_job(st, chunks, lc, level, job, d, begin, end)) return;
+  const uint32_t nl = d->nl, n = d->n, off = d->off;
+  if (nl == n) return;
+  if (threadIdx.x < 12) {
+    const uint32_t child = threadIdx.x / 6, mm = (threadIdx.x / 3) & 1u, c = threadIdx.x % 3;
+    s_red[child][mm][c] = mm ? enc(-FLT_MAX) : enc(FLT_MAX);
+  }
+  __syncthreads();
+  for (uint32_t p = begin + threadIdx.x; p < end; p += blockDim.x) {
+    const uint32_t id = st.tmp[off + p];
+    st.order[off + p] = id;
+    if (nl != 0u) {
+      const uint32_t child = p < nl ? 0u : 1u;
+      for (int c = 0; c < 3; ++c) {
+        atomicMin(&s_red[child][0][c], enc(st.bmin[c][id]));
+        atomicMax(&s_red[child][1][c], enc(st.bmax[c][id]));
       }
     }
   }
+  __syncthreads();
+  if (nl != 0u && threadIdx.x < 12) {
+    const uint32_t child = threadIdx.x / 6, mm = (threadIdx.x / 3) & 1u, c = threadIdx.x % 3;
+    if (mm) atomicMax(&d->box[child][1][c], s_red[child][1][c]);
+    else atomicMin(&d->box[child][0][c], s_red[child][0][c]);
+  }
 }
+// the children of every big node that was split
+__global__ void k_big_children(BuildState st, uint32_t* next, uint32_t* next_count, uint2* next_chunks, uint32_t level, const uint32_t* lc) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= lc[2]) return;
+  const BigSplit& d = st.splits[level & 1u][slot];
+  if (!d.ok || d.nl == 0u || d.nl == d.n) return;   // a leaf (blas.rs:291-293 for the one-sided cases)
+  make_children(st, d.node, d.off, d.n, d.nl, &d.box[0][0][0], next, next_count, next_chunks, level);
+}
+#endif
 
 // A subtree of at most kSeq primitives, finished by one WAVE: the reference's recursion as it stands -- every candidate
 // plane evaluated by a loop over the primitives (evaluate_sah, blas.rs:64-89: the same counts and boxes the bins give,
@@ -832,6 +1047,8 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   for (int i = 0; i < 9; ++i) off_u[i] = reserve(sizeof(uint32_t) * ((size_t)n + 2));
   const size_t off_nodes = reserve(sizeof(DNode) * (2 * (size_t)n + 2)), off_big = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2)), off_counts = reserve(64), off_levels = reserve(sizeof(uint32_t) * 4u * ((size_t)in.max_depth + 2u)), off_gbins = reserve((size_t)max_slots * kBinWords * 4);
   const size_t off_chunks[2] = {reserve((size_t)max_chunks * sizeof(uint2)), reserve((size_t)max_chunks * sizeof(uint2))};
+  const size_t off_splits = reserve(2 * (size_t)max_slots * sizeof(BigSplit)), off_chcnt = reserve(2 * (size_t)max_chunks * sizeof(uint32_t)),
+               off_chbase = reserve(2 * (size_t)max_chunks * sizeof(uint32_t));
   size_t off_layout[8] = {};
   if (keep)
     for (size_t& o : off_layout) o = reserve(sizeof(uint32_t) * (2 * (size_t)n + 2));
@@ -861,6 +1078,9 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   st.slot_count = st.node_count + 4;
   st.gbins = reinterpret_cast<uint32_t*>(base + off_gbins);
   for (int i = 0; i < 2; ++i) st.chunks[i] = reinterpret_cast<uint2*>(base + off_chunks[i]);
+  for (int i = 0; i < 2; ++i) st.splits[i] = reinterpret_cast<BigSplit*>(base + off_splits) + (size_t)i * max_slots;
+  st.ch_cnt = reinterpret_cast<uint32_t*>(base + off_chcnt);
+  st.ch_base = reinterpret_cast<uint32_t*>(base + off_chbase);
   st.small_count = st.node_count + 2;
   uint32_t* const level_counts = reinterpret_cast<uint32_t*>(base + off_levels);   // [level][open nodes, chunks, big slots, -]
   st.seed_origin = in.seed_origin ? 1u : 0u;
@@ -885,6 +1105,7 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
   HB_TRY(hipMemcpyAsync(lists[0], &zero, 4, hipMemcpyHostToDevice, stream));  // level 0: the root
   // the level records: all zero but the root's {one open node, its chunks, one big slot}
   HB_TRY(hipMemsetAsync(level_counts, 0, sizeof(uint32_t) * 4u * ((size_t)in.max_depth + 2u), stream));
+  HB_TRY(hipMemsetAsync(st.splits[0], 0, 2 * (size_t)max_slots * sizeof(BigSplit), stream));   // (the root's chunk_first = 0)
   const uint32_t root_chunks = n > kBig ? (n + kChunk - 1) / kChunk : 0u;
   const uint32_t record0[4] = {n > 0 ? 1u : 0u, root_chunks, n > kBig ? 1u : 0u, 0u};
   HB_TRY(hipMemcpyAsync(level_counts, record0, sizeof record0, hipMemcpyHostToDevice, stream));
@@ -924,6 +1145,20 @@ bool gpu_build_blas(const BlasBuildInput& in, std::vector<uint32_t>& order, std:
       hipLaunchKernelGGL(k_build_level, dim3(bound), dim3(big_possible ? kBuildLevelMaxBlock : kB), 0, stream, sl, lists[level & 1], lists[(level + 1) & 1], lc_next,
                          sl.chunks[(level + 1) & 1], level, lc);
       HB_TRY(hipGetLastError());
+#if RAYCA_BIG_PARTITION
+      if (big_possible) {  // the big nodes' partitions and children, by their chunks (k_build_level has left the decisions)
+        const dim3 cgrid((uint32_t)std::min<uint64_t>(by_depth * ((n + kChunk - 1) / kChunk), max_chunks)), sgrid((uint32_t)((std::min<uint64_t>(by_depth, max_slots) + 63u) / 64u));
+        const uint2* cl = sl.chunks[level & 1];
+        hipLaunchKernelGGL(k_big_count, cgrid, dim3(kB), 0, stream, sl, cl, lc, level);
+        hipLaunchKernelGGL(k_big_classify, cgrid, dim3(kB), 0, stream, sl, cl, lc, level);
+        hipLaunchKernelGGL(k_big_scan, sgrid, dim3(64), 0, stream, sl, lc, level);
+        hipLaunchKernelGGL(k_big_rank, cgrid, dim3(kB), 0, stream, sl, cl, lc, level);
+        hipLaunchKernelGGL(k_big_scatter, cgrid, dim3(kB), 0, stream, sl, cl, lc, level);
+        hipLaunchKernelGGL(k_big_finish, cgrid, dim3(kB), 0, stream, sl, cl, lc, level);
+        hipLaunchKernelGGL(k_big_children, sgrid, dim3(64), 0, stream, sl, lists[(level + 1) & 1], lc_next, sl.chunks[(level + 1) & 1], level, lc);
+        HB_TRY(hipGetLastError());
+      }
+#endif
     }
     lc_host.resize(4u * (batch + 1u));
     HB_TRY(hipMemcpyAsync(lc_host.data(), level_counts + 4u * level0, sizeof(uint32_t) * lc_host.size(), hipMemcpyDeviceToHost, stream));
