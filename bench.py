@@ -282,7 +282,10 @@ def run_workload(env, args, name, steps, warmup, main):
 
         def __init__(self):
             self.counter = 0
-            self.gatherer = FrameGatherer(H, W, args.band_rows, gather_dev)
+            # (one gatherer per context: each has a receive buffer of its own on rank 0 -- the de-interleave of one context's
+            # frame runs on that context's stream while the next context's collective may already be landing)
+            self.gatherers = [FrameGatherer(H, W, args.band_rows, gather_dev) for _ in range(F)]
+            self.gatherer = self.gatherers[0]
             self.sends = [torch.zeros((self.gatherer.max_rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(F)]
             self.frames = [torch.empty((H, W, 4), dtype=torch.uint8, device=gather_dev) if rank == 0 else None for _ in range(F)]
             self.issue = [ds.prepare_device(cfg, W, H, self.sends[c][:my_rows].data_ptr(), 0, tile=tile, stream=streams[c].cuda_stream, context=c) for c in range(F)]
@@ -291,12 +294,13 @@ def run_workload(env, args, name, steps, warmup, main):
         def step(self):
             c = self.counter % F
             self.counter += 1
+            self.last = c
             self.issue[c]()
             with torch.cuda.stream(streams[c]):
                 if backend == "nccl":
-                    return self.gatherer(self.sends[c], out=self.frames[c])
+                    return self.gatherers[c](self.sends[c], out=self.frames[c])
                 streams[c].synchronize()   # rehearsal: gloo gathers host tensors
-                return self.gatherer(self.sends[c].cpu(), out=self.frames[c])
+                return self.gatherers[c](self.sends[c].cpu(), out=self.frames[c])
 
         def drain(self):
             self.counter = 0
@@ -354,11 +358,18 @@ def run_workload(env, args, name, steps, warmup, main):
     rays_rank = counted["rays_primary"] + counted["rays_shadow"] + counted["rays_bounce"]
     algo_bytes = 32 * counted["boxes_tested"] + 36 * counted["triangles_tested"] + 272 * counted["hits_shaded"] + 4 * my_rows * W
 
+    frame_check = None
     if world == 1:
         elapsed = timed(LocalLoop())
         elapsed_batched, B2 = None, 1
     else:
-        elapsed = timed(StreamGatherLoop())                  # `value`: one gather per frame
+        sg = StreamGatherLoop()
+        elapsed = timed(sg)                                  # `value`: one gather per frame
+        if rank == 0:   # the frame rank 0 holds after the last gather == the frame one GPU renders on its own, bit for bit
+            whole = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+            ds.render_device(cfg, W, H, whole.data_ptr(), 0, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            frame_check = bool(torch.equal(sg.frames[sg.last].to(dev), whole))
         B2 = max(1, min(args.gather_batch, 8))
         elapsed_batched = timed(GatherLoop(B2)) if (B2 > 1 and main) else None
 
@@ -498,6 +509,7 @@ def run_workload(env, args, name, steps, warmup, main):
                    "bvh_builder": ("SAH 63 planes x 3 axes as rayca-soft bvh/blas.rs, candidate boxes seeded empty; ties by the reference's primitive order"
                                    if args.builder == "sah" else "reference SAH (rayca-soft bvh/blas.rs:64-123,261-316) incl. origin-seeded candidate boxes"),
                    "rays_per_frame": int(rays_total), "frames_in_flight": F, "tiling": f"rows in bands of {args.band_rows} dealt over {world} rank(s)",
+                   "gathered_frame_equals_one_gpu_frame": frame_check,
                    "frame_gather": (f"torch.distributed.gather ({'RCCL' if backend == 'nccl' else backend}) to rank 0, ONE collective per frame at frame end, behind the frame on the frame's own stream"
                                     if world > 1 else "none"),
                    "launched_by": "torch.distributed.run / environment" if os.environ.get("TORCHELASTIC_RUN_ID") else ("bench.py (rayca_amd/launcher.py)" if world > 1 else "single process")},
