@@ -605,7 +605,7 @@ def main():
             if r is not None:
                 others.append({"workload": r["config"]["workload"], "name": name, "baseline_config": r["config"]["baseline_config"],
                                "Mrays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
-                               "rays_per_frame": r["config"]["rays_per_frame"], "frames_in_flight": r["config"]["frames_in_flight"],
+                               "rays_per_frame": r["config"]["rays_per_frame"], "frames_in_flight": r["config"]["frames_in_flight"], "gathered_frame_equals_one_gpu_frame": r["config"]["gathered_frame_equals_one_gpu_frame"],
                                "triangles": r["config"]["triangles"], "bvh_build_ms": r["config"]["bvh_build_ms"], "node_format": r["config"]["node_format"],
                                "roofline": r["roofline"], **({"latency": r["latency"]} if "latency" in r else {})})
     if rank == 0:
