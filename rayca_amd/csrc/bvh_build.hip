@@ -40,7 +40,10 @@ constexpr int kB = 256;
 // k_build_level runs with 256 threads per node, and with 1024 on the levels that hold nodes above kBig primitives: their
 // partition is one workgroup's loop over the node's range (levels 0-4 of the atrium: 9.0 ms of the 14 with 256 threads)
 constexpr int kBuildLevelMaxBlock = 1024;
-constexpr uint32_t kBig = 16384;    // nodes above this size are binned by many workgroups (k_bin_big), kChunk positions each
+#ifndef RAYCA_KBIG
+#define RAYCA_KBIG 16384
+#endif
+constexpr uint32_t kBig = RAYCA_KBIG;    // nodes above this size are binned by many workgroups (k_bin_big), kChunk positions each
 constexpr uint32_t kChunk = 4096;
 constexpr uint32_t kBinWords = 3 * 64 * 7;  // per node: count + min xyz + max xyz for 64 bins on 3 axes
 constexpr uint32_t kSeq = 16;  // subtrees of at most this many primitives are finished by ONE wave (k_build_small)
